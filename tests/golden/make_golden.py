@@ -1,0 +1,422 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING the reference.
+
+Run only in the build container (the reference is mounted read-only at
+/root/reference and never travels to the GPU box):
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz, api.json
+
+What is captured:
+  G1  single-evaluation known-answer tests: accelerations after __init__ and the full
+      state after one step(), all 7 precision modes, N in {64,257}, D in {2,3}, three
+      softenings, equal/unequal masses.  For the grid modes the input/output of the
+      reference's own `_grid_quantize_safe` / `_grid_quantize` calls are intercepted
+      (spy wrappers around the reference functions, nothing re-implemented) and reduced
+      to lmin/lmax/bin-index matrix/fmin/fmax.
+  G1c CUSTOM levels through the sensitivity_test.py-style subclass override.
+  G2  config-1 trajectory: N=1024, seed 42, create_disk_galaxy ICs -> fp32,
+      G=1e-3, dt=0.01, eps=0.1; float64 snapshots + energies; other modes final state
+      + diagnostics from the reference's metrics.py.
+  G3  tile coverage: N=4096 fp64 50 ticks, N=8192 fp64 5 ticks (final state + energy).
+  G4  API semantics: dtype timeline, fp64-input run, in-place perturbation, subclass
+      override, get_state keys, mode-string alias table.
+  G5  tensor-level hooks: quantize_distance_squared / quantize_force / _grid_quantize*
+      on random tensors.
+
+Only DATA (inputs + outputs) is stored; no reference source text.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+
+import galaxy as ref_galaxy            # noqa: E402
+import metrics as ref_metrics          # noqa: E402
+import quantization as ref_quant       # noqa: E402
+import simulation as ref_sim           # noqa: E402
+from quantization import PrecisionMode  # noqa: E402
+
+torch.set_num_threads(8)
+
+MODES = [PrecisionMode.FLOAT64, PrecisionMode.FLOAT32, PrecisionMode.BFLOAT16,
+         PrecisionMode.FLOAT16, PrecisionMode.INT8_SIM, PrecisionMode.INT4_SIM,
+         PrecisionMode.CUSTOM]
+GRID_LEVELS = {PrecisionMode.INT8_SIM: 256, PrecisionMode.INT4_SIM: 16, PrecisionMode.CUSTOM: 64}
+
+
+def npy(t):
+    if t.dtype == torch.bfloat16:
+        t = t.float()
+    return t.detach().cpu().numpy()
+
+
+class Spy:
+    """Intercepts the reference's grid-quantisation calls to record their tensors."""
+
+    def __init__(self):
+        self.safe = []   # (input, levels, min_val, output)
+        self.lin = []    # (input, levels, output)
+
+    def __enter__(self):
+        self._safe = ref_quant._grid_quantize_safe
+        self._lin = ref_quant._grid_quantize
+
+        def spy_safe(tensor, levels, min_val=0.01):
+            out = self._safe(tensor, levels, min_val)
+            self.safe.append((tensor.clone(), levels, min_val, out.clone()))
+            return out
+
+        def spy_lin(tensor, levels):
+            out = self._lin(tensor, levels)
+            self.lin.append((tensor.clone(), levels, out.clone()))
+            return out
+
+        ref_quant._grid_quantize_safe = spy_safe
+        ref_quant._grid_quantize = spy_lin
+        return self
+
+    def __exit__(self, *a):
+        ref_quant._grid_quantize_safe = self._safe
+        ref_quant._grid_quantize = self._lin
+
+
+def safe_bins(tin, levels, min_val, tout):
+    """Bin indices as the reference computed them (same torch ops on the captured input)."""
+    ts = tin.clamp(min=min_val)
+    lt = torch.log(ts)
+    lmin, lmax = lt.min(), lt.max()
+    if (lmax - lmin) < 1e-10:
+        return None, float(lmin), float(lmax)
+    k = torch.round((lt - lmin) / (lmax - lmin) * (levels - 1))
+    # cross-check against the reference's own output values
+    chk = torch.exp(k / (levels - 1) * (lmax - lmin) + lmin).clamp(min=min_val)
+    assert torch.equal(chk, tout), "bin reconstruction does not reproduce reference output"
+    return npy(k).astype(np.int32), float(lmin), float(lmax)
+
+
+def lin_bins(tin, levels, tout):
+    mn, mx = tin.min(), tin.max()
+    if (mx - mn) < 1e-10:
+        return None, float(mn), float(mx)
+    k = torch.round((tin - mn) / (mx - mn) * (levels - 1))
+    chk = k / (levels - 1) * (mx - mn) + mn
+    assert torch.equal(chk, tout)
+    return npy(k).astype(np.int32), float(mn), float(mx)
+
+
+def make_ics(n, d, seed, unequal):
+    g = torch.Generator().manual_seed(seed)
+    pos = (torch.randn(n, d, generator=g) * 4.0).float()
+    vel = (torch.randn(n, d, generator=g) * 0.05).float()
+    if unequal:
+        mass = (0.2 + 2.0 * torch.rand(n, generator=g)).float()
+    else:
+        mass = torch.ones(n)
+    return pos, vel, mass
+
+
+def g1():
+    cases = [
+        dict(name="n64_d2_e0.1", n=64, d=2, eps=0.1, unequal=False, seed=1),
+        dict(name="n257_d2_e0.05", n=257, d=2, eps=0.05, unequal=True, seed=2),
+        dict(name="n64_d3_e0.01", n=64, d=3, eps=0.01, unequal=False, seed=3),
+        dict(name="n257_d3_e0.1", n=257, d=3, eps=0.1, unequal=True, seed=4),
+    ]
+    for c in cases:
+        pos, vel, mass = make_ics(c["n"], c["d"], c["seed"], c["unequal"])
+        out = dict(pos=npy(pos), vel=npy(vel), mass=npy(mass), eps=c["eps"], G=0.001, dt=0.01)
+        for mode in MODES:
+            with Spy() as spy:
+                sim = ref_sim.GalaxySimulation(pos.clone(), vel.clone(), mass.clone(),
+                                               precision_mode=mode, G=0.001,
+                                               softening=c["eps"], dt=0.01)
+            tag = mode.value
+            out[f"{tag}/acc0"] = npy(sim.accelerations)
+            out[f"{tag}/pe0"] = sim.get_potential_energy()
+            out[f"{tag}/ke0"] = sim.get_kinetic_energy()
+            if mode in GRID_LEVELS:
+                tin, lv, mv, tout = spy.safe[0]
+                assert lv == GRID_LEVELS[mode]
+                k, lmin, lmax = safe_bins(tin, lv, mv, tout)
+                out[f"{tag}/d2bins"] = k.astype(np.int16)
+                out[f"{tag}/lmin"] = lmin
+                out[f"{tag}/lmax"] = lmax
+                out["r2_f32"] = npy(tin)   # identical for the three grid modes (same fp32 inputs)
+                if spy.lin:
+                    fin, flv, fout = spy.lin[0]
+                    fk, fmin, fmax = lin_bins(fin, flv, fout)
+                    out[f"{tag}/fbins"] = fk.astype(np.int16)
+                    out[f"{tag}/fmin"] = fmin
+                    out[f"{tag}/fmax"] = fmax
+                    out[f"{tag}/acc0_prequant"] = npy(fin)
+            sim.step()
+            out[f"{tag}/pos1"] = npy(sim.positions)
+            out[f"{tag}/vel1"] = npy(sim.velocities)
+            out[f"{tag}/acc1"] = npy(sim.accelerations)
+            for _ in range(9):
+                sim.step()
+            out[f"{tag}/pos10"] = npy(sim.positions)
+            out[f"{tag}/vel10"] = npy(sim.velocities)
+            out[f"{tag}/e10"] = np.array([sim.get_kinetic_energy(), sim.get_potential_energy()])
+        np.savez_compressed(os.path.join(OUT, f"g1_{c['name']}.npz"), **out)
+        print("G1", c["name"])
+
+
+def g1c():
+    """CUSTOM levels via the subclass-override idiom of the reference's sweep scripts."""
+    from quantization import _grid_quantize_safe
+
+    class CustomQuantSim(ref_sim.GalaxySimulation):
+        def __init__(self, *args, quant_levels, **kwargs):
+            self.quant_levels = quant_levels
+            super().__init__(*args, **kwargs)
+
+        def _compute_accelerations(self):
+            pos = self.positions
+            diff = pos.unsqueeze(0) - pos.unsqueeze(1)
+            dist_sq = (diff ** 2).sum(dim=-1) + self.softening_sq
+            if self.quant_levels < 10000:
+                dist_sq = _grid_quantize_safe(dist_sq, self.quant_levels, min_val=0.01)
+            ff = self.G / dist_sq ** 1.5
+            ff = ff * self.masses.unsqueeze(0)
+            ff = ff * (1 - torch.eye(self.num_stars, device=self.device))
+            return (ff.unsqueeze(-1) * diff).sum(dim=1)
+
+    pos, vel, mass = make_ics(257, 2, 11, True)
+    out = dict(pos=npy(pos), vel=npy(vel), mass=npy(mass), eps=0.1, G=0.001, dt=0.01)
+    for L in (4, 64, 1000):
+        sim = CustomQuantSim(pos.clone(), vel.clone(), mass.clone(), quant_levels=L,
+                             precision_mode=PrecisionMode.FLOAT32, G=0.001, dt=0.01, softening=0.1)
+        out[f"L{L}/acc0"] = npy(sim.accelerations)
+        for _ in range(5):
+            sim.step()
+        out[f"L{L}/pos5"] = npy(sim.positions)
+        out[f"L{L}/vel5"] = npy(sim.velocities)
+    np.savez_compressed(os.path.join(OUT, "g1c_custom_levels.npz"), **out)
+    print("G1c")
+
+
+def diagnostics(sim):
+    rc = ref_metrics.compute_rotation_curve(sim.positions, sim.velocities)
+    return dict(
+        ke=sim.get_kinetic_energy(), pe=sim.get_potential_energy(), e=sim.get_total_energy(),
+        r90=ref_metrics.compute_galaxy_radius(sim.positions, 90),
+        bound=ref_metrics.compute_bound_fraction(sim.positions, sim.velocities, sim.masses, sim.G),
+        disp=ref_metrics.compute_velocity_dispersion(sim.velocities),
+        rc_r=np.asarray(rc["radii"], dtype=np.float64),
+        rc_v=np.asarray(rc["velocities"], dtype=np.float64),
+        rc_n=np.asarray(rc["num_stars_per_bin"], dtype=np.int64),
+    )
+
+
+def disk_ics(n, seed):
+    torch.manual_seed(seed)
+    p, v, m = ref_galaxy.create_disk_galaxy(num_stars=n, galaxy_radius=10.0, device=torch.device("cpu"))
+    return p.float(), v.float(), m.float()
+
+
+def g2():
+    pos, vel, mass = disk_ics(1024, 42)
+    out = dict(pos=npy(pos), vel=npy(vel), mass=npy(mass), eps=0.1, G=0.001, dt=0.01)
+    snaps = (0, 1, 10, 100, 200)
+    for mode in MODES:
+        tag = mode.value
+        sim = ref_sim.GalaxySimulation(pos.clone(), vel.clone(), mass.clone(), precision_mode=mode,
+                                       G=0.001, dt=0.01, softening=0.1)
+        for t in range(0, 201):
+            if t > 0:
+                sim.step()
+            if t in snaps and (mode == PrecisionMode.FLOAT64 or t in (0, 10, 200)):
+                out[f"{tag}/pos{t}"] = npy(sim.positions)
+                out[f"{tag}/vel{t}"] = npy(sim.velocities)
+                if mode == PrecisionMode.FLOAT64:
+                    out[f"{tag}/acc{t}"] = npy(sim.accelerations)
+            if t in (0, 100, 200):
+                for k, v in diagnostics(sim).items():
+                    out[f"{tag}/diag{t}/{k}"] = v
+        print("G2", tag)
+    np.savez_compressed(os.path.join(OUT, "g2_config1_n1024.npz"), **out)
+
+
+def g3():
+    for n, ticks in ((4096, 50), (8192, 5)):
+        pos, vel, mass = disk_ics(n, 42)
+        sim = ref_sim.GalaxySimulation(pos.clone(), vel.clone(), mass.clone(),
+                                       precision_mode=PrecisionMode.FLOAT64, G=0.001, dt=0.01, softening=0.1)
+        e0 = np.array([sim.get_kinetic_energy(), sim.get_potential_energy()])
+        acc0 = npy(sim.accelerations)
+        for _ in range(ticks):
+            sim.step()
+        e1 = np.array([sim.get_kinetic_energy(), sim.get_potential_energy()])
+        np.savez_compressed(os.path.join(OUT, f"g3_fp64_n{n}.npz"), pos=npy(pos), vel=npy(vel), mass=npy(mass),
+                            eps=0.1, G=0.001, dt=0.01, ticks=ticks, acc0=acc0, e0=e0, e1=e1,
+                            pos_final=npy(sim.positions), vel_final=npy(sim.velocities),
+                            acc_final=npy(sim.accelerations))
+        print("G3", n)
+
+
+def g4():
+    api = {}
+    pos, vel, mass = make_ics(96, 2, 21, True)
+    out = dict(pos=npy(pos), vel=npy(vel), mass=npy(mass), eps=0.1, G=0.001, dt=0.01)
+
+    # dtype timeline, fp32 inputs, every mode
+    tl = {}
+    for mode in MODES:
+        sim = ref_sim.GalaxySimulation(pos.clone(), vel.clone(), mass.clone(), precision_mode=mode)
+        row = [[str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.accelerations.dtype)]]
+        for _ in range(2):
+            sim.step()
+            row.append([str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.accelerations.dtype)])
+        tl[mode.value] = row
+    api["dtype_timeline_fp32_inputs"] = tl
+
+    # fp64 inputs (hardware_leak_test.py-style), FLOAT64 and FLOAT32 modes
+    tl64 = {}
+    for mode in MODES:
+        sim = ref_sim.GalaxySimulation(pos.double(), vel.double(), mass.double(), precision_mode=mode,
+                                       G=0.001, dt=0.01, softening=0.1)
+        row = [[str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.accelerations.dtype)]]
+        out[f"in64/{mode.value}/acc0"] = npy(sim.accelerations)
+        for _ in range(3):
+            sim.step()
+        row.append([str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.accelerations.dtype)])
+        tl64[mode.value] = row
+        out[f"in64/{mode.value}/pos3"] = npy(sim.positions)
+        out[f"in64/{mode.value}/vel3"] = npy(sim.velocities)
+        out[f"in64/{mode.value}/e3"] = np.array([sim.get_kinetic_energy(), sim.get_potential_energy()])
+    api["dtype_timeline_fp64_inputs"] = tl64
+
+    # half-precision state (omega_point_test.py-style): FLOAT32 mode, f16 / bf16 inputs
+    tlh = {}
+    for name, dt_ in (("float16", torch.float16), ("bfloat16", torch.bfloat16)):
+        sim = ref_sim.GalaxySimulation(pos.to(dt_), vel.to(dt_), mass.to(dt_),
+                                       precision_mode=PrecisionMode.FLOAT32, G=0.001, dt=0.01, softening=0.1)
+        row = [[str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.accelerations.dtype)]]
+        out[f"in_{name}/acc0"] = npy(sim.accelerations)
+        out[f"in_{name}/pe0"] = sim.get_potential_energy()
+        for _ in range(3):
+            sim.step()
+        row.append([str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.accelerations.dtype)])
+        tlh[name] = row
+        out[f"in_{name}/pos3"] = npy(sim.positions)
+        out[f"in_{name}/vel3"] = npy(sim.velocities)
+    api["dtype_timeline_half_inputs_float32_mode"] = tlh
+
+    # in-place perturbation between steps (omega_point_test.py butterfly idiom)
+    sim = ref_sim.GalaxySimulation(pos.clone(), vel.clone(), mass.clone(), precision_mode=PrecisionMode.FLOAT32,
+                                   G=0.001, dt=0.01, softening=0.1)
+    sim.positions[0, 0] += 1e-3
+    sim.step()
+    sim.positions[5, 1] -= 2e-3
+    sim.velocities[7, 0] += 1e-2
+    sim.step()
+    out["mutate/pos2"] = npy(sim.positions)
+    out["mutate/vel2"] = npy(sim.velocities)
+
+    # attribute changes between steps (dt / G / softening_sq are read every step)
+    sim = ref_sim.GalaxySimulation(pos.clone(), vel.clone(), mass.clone(), precision_mode=PrecisionMode.FLOAT64,
+                                   G=0.001, dt=0.01, softening=0.1)
+    sim.step()
+    sim.dt = 0.02
+    sim.step()
+    sim.G = 0.002
+    sim.step()
+    out["attrs/pos3"] = npy(sim.positions)
+    out["attrs/vel3"] = npy(sim.velocities)
+
+    # run() callback contract
+    calls = []
+    sim = ref_sim.GalaxySimulation(pos.clone(), vel.clone(), mass.clone())
+    sim.run(25, callback=lambda s, t: calls.append(int(t)), callback_interval=10)
+    api["run_callback_ticks_25_by_10"] = calls
+    api["tick_after_run"] = sim.tick
+    st = sim.get_state()
+    api["get_state_keys"] = sorted(st.keys())
+    api["get_state_precision_mode"] = st["precision_mode"]
+
+    # run_comparison structure
+    res = ref_sim.run_comparison(pos.clone(), vel.clone(), mass.clone(),
+                                 [PrecisionMode.FLOAT64, PrecisionMode.INT4_SIM], num_ticks=20,
+                                 callback_interval=10)
+    api["run_comparison_keys"] = sorted(res.keys())
+    api["run_comparison_entry_keys"] = sorted(res["float64"].keys())
+    api["run_comparison_history_ticks"] = res["float64"]["history"]["ticks"]
+    out["runcmp/float64/energies"] = np.array(res["float64"]["history"]["energies"])
+    out["runcmp/int4_sim/energies"] = np.array(res["int4_sim"]["history"]["energies"])
+    out["runcmp/float64/pos_final"] = npy(res["float64"]["final_state"]["positions"])
+
+    # string helpers
+    names = ["float64", "float32", "bfloat16", "bf16", "float16", "fp16", "int8", "int8_sim", "int4",
+             "int4_sim", "custom", "FLOAT32", "Int4", "nonsense", ""]
+    api["mode_from_string"] = {s: ref_quant.get_mode_from_string(s).value for s in names}
+    api["describe_mode"] = {m.value: ref_quant.describe_mode(m) for m in MODES}
+    api["precision_mode_members"] = {m.name: m.value for m in PrecisionMode}
+
+    np.savez_compressed(os.path.join(OUT, "g4_api.npz"), **out)
+    with open(os.path.join(OUT, "api.json"), "w") as f:
+        json.dump(api, f, indent=1, sort_keys=True)
+    print("G4")
+
+
+def g5():
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    d2 = (torch.rand(128, 128, generator=g) * 50.0 + 0.001).float()
+    d2[3, 4] = 1e-5
+    d2[10, 10] = 70000.0   # overflows fp16
+    force = (torch.randn(300, 2, generator=g) * 0.01).float()
+    out["d2"] = npy(d2)
+    out["force"] = npy(force)
+    for mode in MODES:
+        out[f"qd2/{mode.value}"] = npy(ref_quant.quantize_distance_squared(d2, mode))
+        out[f"qf/{mode.value}"] = npy(ref_quant.quantize_force(force, mode))
+    for L in (4, 16, 100, 1000):
+        out[f"qd2/custom{L}"] = npy(ref_quant.quantize_distance_squared(d2, PrecisionMode.CUSTOM, custom_levels=L))
+        out[f"safe/L{L}_min0.5"] = npy(ref_quant._grid_quantize_safe(d2, L, min_val=0.5))
+        out[f"lin/L{L}"] = npy(ref_quant._grid_quantize(force, L))
+    const = torch.full((7, 7), 3.0)
+    out["safe/const"] = npy(ref_quant._grid_quantize_safe(const, 16))
+    out["lin/const"] = npy(ref_quant._grid_quantize(const, 16))
+    # fp64 tensors through the same hooks
+    out["qd2_64/int8_sim"] = npy(ref_quant.quantize_distance_squared(d2.double(), PrecisionMode.INT8_SIM))
+    out["qd2_64/float16"] = npy(ref_quant.quantize_distance_squared(d2.double(), PrecisionMode.FLOAT16))
+    np.savez_compressed(os.path.join(OUT, "g5_hooks.npz"), **out)
+    print("G5")
+
+
+def g6():
+    """Initial-condition generators and diagnostics (galaxy.py / metrics.py), seeded."""
+    out = {}
+    for name, fn, kw in (("disk", ref_galaxy.create_disk_galaxy, dict(num_stars=2000)),
+                         ("test", ref_galaxy.create_test_galaxy, dict(num_stars=1000)),
+                         ("halo", ref_galaxy.create_galaxy_with_halo, dict(num_stars=1500))):
+        torch.manual_seed(7)
+        p, v, m = fn(device=torch.device("cpu"), **kw)
+        out[f"{name}/pos"], out[f"{name}/vel"], out[f"{name}/mass"] = npy(p), npy(v), npy(m)
+        rc = ref_metrics.compute_rotation_curve(p, v)
+        out[f"{name}/rc_r"], out[f"{name}/rc_v"] = rc["radii"], rc["velocities"]
+        out[f"{name}/rc_n"] = np.asarray(rc["num_stars_per_bin"])
+        rc2 = ref_metrics.compute_rotation_curve(p, v, num_bins=7, max_radius=12.5)
+        out[f"{name}/rc7_v"] = rc2["velocities"]
+        out[f"{name}/r90"] = ref_metrics.compute_galaxy_radius(p, 90)
+        out[f"{name}/r50"] = ref_metrics.compute_galaxy_radius(p, 50)
+        out[f"{name}/bound"] = ref_metrics.compute_bound_fraction(p, v, m, 0.001)
+        out[f"{name}/disp"] = ref_metrics.compute_velocity_dispersion(v)
+    r = torch.linspace(0.1, 100, 50)
+    out["nfw"] = npy(ref_galaxy.nfw_enclosed_mass(r, 5000.0, 30.0))
+    out["nfw_r"] = npy(r)
+    np.savez_compressed(os.path.join(OUT, "g6_galaxy_metrics.npz"), **out)
+    print("G6")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6"]
+    for w in which:
+        globals()[w]()

@@ -1,0 +1,265 @@
+"""Pins the CPU oracle (oracle/) to golden vectors produced by RUNNING the reference
+(tests/golden/make_golden.py).  CPU only.
+
+Tolerances (relative to max|reference| of the compared array unless noted):
+  * FLOAT64 mode: 1e-13 single evaluation / short runs (observed <= 1e-15), trajectory
+    bounds follow the reference's own self-noise floor.
+  * fp32-family modes: 1e-6 single evaluation (observed <= 3e-7: torch SLEEF pow/exp vs
+    correctly rounded, and torch's fp32 cascade sum vs double accumulation).
+  * distance-bin indices, lmin/lmax: bit-exact.  Force bins: mismatch count reported, and
+    bounded (they depend on the fp32 summation order of the reference).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+from oracle import oracle as O
+
+MODES = ["float64", "float32", "bfloat16", "float16", "int8_sim", "int4_sim", "custom"]
+GRID = ["int8_sim", "int4_sim", "custom"]
+G1 = ["g1_n64_d2_e0.1.npz", "g1_n257_d2_e0.05.npz", "g1_n64_d3_e0.01.npz", "g1_n257_d3_e0.1.npz"]
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def tol_single(mode):
+    return 1e-13 if mode == "float64" else 1e-6
+
+
+@pytest.mark.parametrize("fname", G1)
+@pytest.mark.parametrize("mode", MODES)
+def test_g1_single_evaluation(fname, mode):
+    g = load_golden(fname)
+    eps = float(g["eps"])
+    acc, dbg = O.accelerations(g["pos"], g["mass"], mode, softening=eps, debug=True)
+    ref = g[f"{mode}/acc0"]
+    assert acc.dtype == ref.dtype
+    if mode in GRID:
+        assert dbg["lmin"] == float(g[f"{mode}/lmin"])
+        assert dbg["lmax"] == float(g[f"{mode}/lmax"])
+        assert np.array_equal(dbg["d2bins"], g[f"{mode}/d2bins"])          # bit-identical bins
+    if mode in ("int8_sim", "int4_sim"):
+        assert relerr(dbg["acc_prequant"], g[f"{mode}/acc0_prequant"]) < 1e-6
+        assert abs(dbg["fmin"] - float(g[f"{mode}/fmin"])) <= 1e-6 * abs(float(g[f"{mode}/fmin"]))
+        assert abs(dbg["fmax"] - float(g[f"{mode}/fmax"])) <= 1e-6 * abs(float(g[f"{mode}/fmax"]))
+        flips = int((dbg["fbins"] != g[f"{mode}/fbins"]).sum())
+        assert flips <= 2, f"{flips} force-bin flips"
+        if flips == 0:
+            assert relerr(acc, ref) < 1e-6
+    else:
+        assert relerr(acc, ref) < tol_single(mode)
+
+
+@pytest.mark.parametrize("fname", G1)
+def test_g1_r2_bit_exact(fname):
+    """fp32 distance-squared matrix (no FMA, reference op order) is bit-identical."""
+    g = load_golden(fname)
+    pos = g["pos"].astype(np.float32)
+    diff = pos[None, :, :] - pos[:, None, :]
+    sq = diff * diff
+    s = sq[..., 0]
+    for k in range(1, pos.shape[1]):
+        s = s + sq[..., k]
+    r2 = s + np.float32(float(g["eps"]) ** 2)
+    assert np.array_equal(r2, g["r2_f32"])
+    # and the oracle's own rounding model agrees with native float arithmetic
+    out, bins, lmin, lmax = O.grid_quantize_safe(g["r2_f32"], 256, bins=True)
+    assert np.array_equal(bins, g["int8_sim/d2bins"])
+
+
+@pytest.mark.parametrize("fname", G1)
+@pytest.mark.parametrize("mode", MODES)
+def test_g1_step_and_energy(fname, mode):
+    g = load_golden(fname)
+    sim = O.OracleSim(g["pos"], g["vel"], g["mass"], mode, G=float(g["G"]), softening=float(g["eps"]),
+                      dt=float(g["dt"]))
+    tol = 1e-13 if mode == "float64" else 2e-6
+    assert abs(sim.get_potential_energy() - float(g[f"{mode}/pe0"])) <= 2e-6 * abs(float(g[f"{mode}/pe0"]))
+    assert abs(sim.get_kinetic_energy() - float(g[f"{mode}/ke0"])) <= 2e-6 * abs(float(g[f"{mode}/ke0"]))
+    sim.step()
+    assert sim.positions.dtype == g[f"{mode}/pos1"].dtype
+    assert sim.velocities.dtype == g[f"{mode}/vel1"].dtype
+    assert relerr(sim.positions, g[f"{mode}/pos1"]) < tol
+    assert relerr(sim.velocities, g[f"{mode}/vel1"]) < tol
+    if mode not in ("int8_sim", "int4_sim"):
+        assert relerr(sim.accelerations, g[f"{mode}/acc1"]) < max(tol, 1e-6 if mode != "float64" else 0)
+    sim.run(9)
+    t10 = 1e-12 if mode == "float64" else (1e-5 if mode not in ("int8_sim", "int4_sim") else 2e-3)
+    assert relerr(sim.positions, g[f"{mode}/pos10"]) < t10
+    assert relerr(sim.velocities, g[f"{mode}/vel10"]) < t10 * 50
+
+
+def test_g1_fp64_energy_exact():
+    g = load_golden(G1[1])
+    sim = O.OracleSim(g["pos"], g["vel"], g["mass"], "float64", softening=float(g["eps"]))
+    # fp32 state at tick 0: energies are fp32-typed in the reference
+    assert abs(sim.get_potential_energy() - float(g["float64/pe0"])) <= 1e-6 * abs(float(g["float64/pe0"]))
+    sim.run(10)
+    ke, pe = g["float64/e10"]
+    assert abs(sim.get_kinetic_energy() - ke) <= 1e-13 * abs(ke)
+    assert abs(sim.get_potential_energy() - pe) <= 1e-13 * abs(pe)
+
+
+@pytest.mark.parametrize("L", [4, 64, 1000])
+def test_g1c_custom_levels_override_semantics(L):
+    """sensitivity_test.py:55-76 pattern == CUSTOM mode with `levels`, no force quantisation."""
+    g = load_golden("g1c_custom_levels.npz")
+    sim = O.OracleSim(g["pos"], g["vel"], g["mass"], "custom", levels=L)
+    assert relerr(sim.accelerations, g[f"L{L}/acc0"]) < 1e-6
+    sim.run(5)
+    assert relerr(sim.positions, g[f"L{L}/pos5"]) < 1e-5
+
+
+def test_g2_config1_fp64_trajectory():
+    """Config 1 (N=1024, 200 ticks, float64): particle-level parity at every snapshot."""
+    g = load_golden("g2_config1_n1024.npz")
+    sim = O.OracleSim(g["pos"], g["vel"], g["mass"], "float64")
+    scale = np.abs(g["float64/pos200"]).max()
+    bounds = {0: 1e-15, 1: 1e-14, 10: 1e-13, 100: 1e-12, 200: 1e-11}   # reference self-noise: 1.2e-15 @200
+    t = 0
+    for snap in (0, 1, 10, 100, 200):
+        sim.run(snap - t)
+        t = snap
+        assert np.abs(sim.positions.astype(np.float64) - g[f"float64/pos{snap}"]).max() / scale < bounds[snap]
+        assert relerr(sim.velocities, g[f"float64/vel{snap}"]) < bounds[snap] * 100
+        if snap in (0, 100, 200):
+            for key, fn in (("ke", sim.get_kinetic_energy), ("pe", sim.get_potential_energy)):
+                ref = float(g[f"float64/diag{snap}/{key}"])
+                tol = 1e-6 if snap == 0 else 1e-12     # tick 0 energies are fp32-typed upstream
+                assert abs(fn() - ref) <= tol * abs(ref)
+    e0 = float(g["float64/diag100/e"])
+    e1 = float(g["float64/diag200/e"])
+    drift_ref = (e1 - e0) / abs(e0)
+    # energy-drift parity (north_star: 1e-10)
+    sim2 = O.OracleSim(g["pos"], g["vel"], g["mass"], "float64")
+    sim2.run(100)
+    a = sim2.get_total_energy()
+    sim2.run(100)
+    b = sim2.get_total_energy()
+    assert abs((b - a) / abs(a) - drift_ref) < 1e-10
+
+
+@pytest.mark.parametrize("mode", MODES[1:])
+def test_g2_config1_other_modes_short_horizon(mode):
+    g = load_golden("g2_config1_n1024.npz")
+    sim = O.OracleSim(g["pos"], g["vel"], g["mass"], mode)
+    sim.run(10)
+    tol = 5e-6 if mode not in ("int8_sim", "int4_sim") else 5e-3
+    assert relerr(sim.positions, g[f"{mode}/pos10"]) < tol
+
+
+@pytest.mark.parametrize("n", [4096])
+def test_g3_fast_path_matches_reference(n):
+    g = load_golden(f"g3_fp64_n{n}.npz")
+    pos, mass = g["pos"], g["mass"]
+    # first evaluation in FLOAT64 mode uses fp32 d/r2: generic oracle
+    acc0 = O.accelerations(pos[:512] if False else pos, mass, "float64")
+    assert relerr(acc0, g["acc0"]) < 1e-13
+    # all-fp64 fast path vs the generic restatement on the final (fp64) state
+    pf = g["pos_final"]
+    fast = O.accelerations_f64_fast(pf, mass.astype(np.float64))
+    assert relerr(fast, g["acc_final"]) < 1e-13
+    pe = O.potential_energy_f64_fast(pf, mass.astype(np.float64))
+    assert abs(pe - g["e1"][1]) <= 1e-13 * abs(g["e1"][1])
+
+
+def test_g3_n8192_final_forces():
+    g = load_golden("g3_fp64_n8192.npz")
+    fast = O.accelerations_f64_fast(g["pos_final"], g["mass"].astype(np.float64))
+    assert relerr(fast, g["acc_final"]) < 1e-13
+
+
+def test_g4_dtype_state_machine_and_mixed_inputs():
+    api = json.load(open(os.path.join(GOLDEN, "api.json")))
+    g = load_golden("g4_api.npz")
+    names = {O.F16: "torch.float16", O.BF16: "torch.bfloat16", O.F32: "torch.float32", O.F64: "torch.float64"}
+    for mode in MODES:
+        sim = O.OracleSim(g["pos"], g["vel"], g["mass"], mode)
+        rows = [[names[c] for c in (sim.codes[0], sim.codes[1], sim.codes[3])]]
+        for _ in range(2):
+            sim.step()
+            rows.append([names[c] for c in (sim.codes[0], sim.codes[1], sim.codes[3])])
+        assert rows == api["dtype_timeline_fp32_inputs"][mode], mode
+        # fp64 inputs
+        sim = O.OracleSim(g["pos"].astype(np.float64), g["vel"].astype(np.float64),
+                          g["mass"].astype(np.float64), mode)
+        tol = 1e-13 if mode == "float64" else 1e-6
+        if mode not in ("int8_sim", "int4_sim"):
+            assert relerr(sim.accelerations, g[f"in64/{mode}/acc0"]) < tol, mode
+        r0 = [names[c] for c in (sim.codes[0], sim.codes[1], sim.codes[3])]
+        sim.run(3)
+        r1 = [names[c] for c in (sim.codes[0], sim.codes[1], sim.codes[3])]
+        assert [r0, r1] == api["dtype_timeline_fp64_inputs"][mode], mode
+        if mode not in ("int8_sim", "int4_sim"):
+            assert relerr(sim.positions, g[f"in64/{mode}/pos3"]) < 1e-6
+            ke, pe = g[f"in64/{mode}/e3"]
+            assert abs(sim.get_potential_energy() - pe) <= 1e-6 * abs(pe)
+            assert abs(sim.get_kinetic_energy() - ke) <= 1e-5 * abs(ke)
+
+
+@pytest.mark.parametrize("name,code", [("float16", O.F16), ("bfloat16", O.BF16)])
+def test_g4_half_precision_state(name, code):
+    """omega_point_test.py:722-733: f16/bf16 state tensors in FLOAT32 mode."""
+    api = json.load(open(os.path.join(GOLDEN, "api.json")))
+    g = load_golden("g4_api.npz")
+    import torch
+    tdt = getattr(torch, name)
+    rd = lambda a: torch.from_numpy(a).to(tdt).float().numpy()   # values representable in the half type
+    sim = O.OracleSim(rd(g["pos"]), rd(g["vel"]), rd(g["mass"]), "float32", codes=(code, code, code))
+    ref = g[f"in_{name}/acc0"]
+    assert relerr(sim.accelerations, ref) < 2e-6
+    assert abs(sim.get_potential_energy() - float(g[f"in_{name}/pe0"])) <= 4e-3 * abs(float(g[f"in_{name}/pe0"]))
+    sim.run(3)
+    names = {O.F16: "torch.float16", O.BF16: "torch.bfloat16", O.F32: "torch.float32", O.F64: "torch.float64"}
+    assert [names[c] for c in (sim.codes[0], sim.codes[1], sim.codes[3])] == \
+        api["dtype_timeline_half_inputs_float32_mode"][name][1]
+    assert relerr(sim.positions, g[f"in_{name}/pos3"]) < 1e-5
+
+
+def test_g5_tensor_hooks():
+    g = load_golden("g5_hooks.npz")
+    d2, force = g["d2"], g["force"]
+    for mode in MODES:
+        out = O.quantize_distance_squared(d2, mode)
+        ref = g[f"qd2/{mode}"]
+        assert out.dtype == ref.dtype
+        if mode in GRID:
+            assert relerr(out, ref) < 1e-6
+        else:
+            assert np.array_equal(out, ref)          # casts are exact (inf on fp16 overflow too)
+        outf = O.quantize_force(force, mode)
+        reff = g[f"qf/{mode}"]
+        if mode in GRID:
+            assert relerr(outf, reff) < 1e-6
+        else:
+            assert np.array_equal(outf, reff)
+    for L in (4, 16, 100, 1000):
+        assert relerr(O.quantize_distance_squared(d2, "custom", custom_levels=L), g[f"qd2/custom{L}"]) < 1e-6
+        assert relerr(O.grid_quantize_safe(d2, L, min_val=0.5), g[f"safe/L{L}_min0.5"]) < 1e-6
+        assert relerr(O.grid_quantize(force, L), g[f"lin/L{L}"]) < 1e-6
+    const = np.full((7, 7), 3.0, np.float32)
+    assert np.array_equal(O.grid_quantize_safe(const, 16), g["safe/const"])
+    assert np.array_equal(O.grid_quantize(const, 16), g["lin/const"])
+    assert relerr(O.quantize_distance_squared(d2.astype(np.float64), "int8_sim"), g["qd2_64/int8_sim"]) < 1e-13
+    assert np.array_equal(O.quantize_distance_squared(d2.astype(np.float64), "float16"), g["qd2_64/float16"])
+
+
+def test_j_range_partials_sum_to_full():
+    g = load_golden(G1[1])
+    pos, mass = g["pos"], g["mass"]
+    full = O.accelerations(pos, mass, "float64", softening=0.05)
+    n = pos.shape[0]
+    parts = [O.accelerations(pos, mass, "float64", softening=0.05, j_range=(a, b), force_quant=False)
+             for a, b in ((0, 100), (100, 200), (200, n))]
+    assert relerr(sum(parts), full) < 1e-14
+    f64 = O.accelerations_f64_fast(pos.astype(np.float64), mass.astype(np.float64), softening=0.05)
+    p64 = sum(O.accelerations_f64_fast(pos.astype(np.float64), mass.astype(np.float64), softening=0.05, j_range=r)
+              for r in ((0, 128), (128, n)))
+    assert relerr(p64, f64) < 1e-14
