@@ -1,0 +1,178 @@
+/*
+ * nbody_amd.h -- C-ABI of the MI355X-native direct-summation N-body engine.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * (nuclearbombmods/nbody-cosmological-simulation) has no FFI layer of its own: its operator
+ * boundary is the Python class `GalaxySimulation` (simulation.py:12) plus the module-level
+ * precision hooks of quantization.py.  Every entry point below names the reference
+ * interface it replaces; the Python binding a maintainer would add is a ctypes stub
+ * (INTEGRATION.md, and nbody_cosmological_simulation_amd/_native.py in this repo).
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 (NB_OK) or a negative nb_status and
+ *     leaves a thread-local message retrievable with nb_last_error();
+ *   - the caller owns every buffer it passes in (host or device, flagged per call); the
+ *     library owns the per-handle device state;
+ *   - a handle is bound to one HIP device and one stream; distinct handles may be used
+ *     concurrently from different threads, one handle must not be;
+ *   - NaN/Inf propagate exactly as IEEE arithmetic dictates; nothing traps;
+ *   - there is NO CPU fallback: without a HIP device nb_create() fails with NB_ERR_NO_DEVICE.
+ */
+#ifndef NBODY_AMD_H
+#define NBODY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NB_ABI_VERSION 1
+
+typedef enum nb_status {
+    NB_OK = 0,
+    NB_ERR_INVALID = -1,       /* bad argument / shape / dtype                     */
+    NB_ERR_NO_DEVICE = -2,     /* no HIP device, or device ordinal out of range    */
+    NB_ERR_HIP = -3,           /* a HIP runtime call failed (message has details)  */
+    NB_ERR_OOM = -4,           /* device allocation failed                         */
+    NB_ERR_UNSUPPORTED = -5,   /* combination not implemented yet (message says)   */
+    NB_ERR_COMM = -6           /* RCCL failure                                     */
+} nb_status;
+
+/* element types of caller buffers and of the Python-visible state tensors */
+typedef enum nb_dtype { NB_F16 = 0, NB_BF16 = 1, NB_F32 = 2, NB_F64 = 3 } nb_dtype;
+
+/* quantization.py:10-18 `PrecisionMode` (same order as the enum's declaration) */
+typedef enum nb_mode {
+    NB_FLOAT64 = 0, NB_FLOAT32 = 1, NB_BFLOAT16 = 2, NB_FLOAT16 = 3,
+    NB_INT8_SIM = 4, NB_INT4_SIM = 5, NB_CUSTOM = 6
+} nb_mode;
+
+typedef struct nb_sim nb_sim;   /* opaque handle == one GalaxySimulation instance */
+
+/* constructor arguments of GalaxySimulation.__init__ (simulation.py:31-40) */
+typedef struct nb_config {
+    int32_t n;             /* num_stars                                                     */
+    int32_t dim;           /* 2 or 3 (positions are (n, dim) row-major)                     */
+    int32_t mode;          /* nb_mode                                                       */
+    int32_t levels;        /* CUSTOM grid levels; 0 -> 64 (quantization.py:66)              */
+    double  G;             /* gravitational constant                                        */
+    double  softening_sq;  /* softening**2 evaluated in Python double (simulation.py:59)    */
+    double  dt;            /* time step                                                     */
+    int32_t device;        /* HIP device ordinal                                            */
+    int32_t rank;          /* j-block shard index   (0 for a single GPU)                    */
+    int32_t nranks;        /* number of shards      (1 for a single GPU)                    */
+    int32_t flags;         /* NB_FLAG_*                                                     */
+} nb_config;
+
+#define NB_FLAG_PROFILE       1   /* bracket every force launch with HIP events (nb_kernel_time) */
+#define NB_FLAG_CUSTOM_FORCEQ 2   /* CUSTOM mode also quantises forces (never set by the stock class) */
+#define NB_FLAG_NO_COMM       4   /* nranks > 1 without RCCL: nb_compute_accelerations leaves this rank's
+                                     PARTIAL sums (no all-reduce, no force quantisation) for the caller
+                                     to reduce; nb_step is refused.  Used by single-GPU shard tests.   */
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+
+/* GalaxySimulation.__init__ (simulation.py:31-72) minus the state upload and first force. */
+int nb_create(nb_sim **out, const nb_config *cfg);
+int nb_destroy(nb_sim *s);
+
+/* attribute writes `sim.G = ..`, `sim.dt = ..`, `sim.softening_sq = ..` between steps
+ * (crash_point_test.py, falsification_tests.py read/write them; simulation.py reads them
+ * at every use :86,:101,:132-141). */
+int nb_set_params(nb_sim *s, double G, double softening_sq, double dt);
+
+/* ---- state --------------------------------------------------------------------------- */
+
+/* simulation.py:63-65 (clone -> device).  pos/vel: n*dim elements, mass: n elements, all of
+ * `dtype`; `on_device` != 0 means the pointers are device pointers on the handle's device.
+ * Any of pos/vel/mass may be NULL to leave that array untouched (re-upload after an
+ * in-place edit such as omega_point_test.py:738). */
+int nb_set_state(nb_sim *s, const void *pos, const void *vel, const void *mass,
+                 int dtype, int on_device);
+
+/* Writes the Python-visible tensors: each non-NULL destination receives the array in its
+ * CURRENT logical dtype (query with nb_state_dtypes).  Synchronises the handle's stream. */
+int nb_get_state(nb_sim *s, void *pos, void *vel, void *acc, void *mass, int on_device);
+
+/* dtypes[4] = {positions, velocities, masses, accelerations} as the reference would report
+ * them at this moment (SURVEY.md section 8a "Facts": fp32 state is promoted to fp64 by the
+ * first step() in FLOAT64 mode, accelerations are fp64 from __init__ on). */
+int nb_state_dtypes(nb_sim *s, int32_t dtypes[4]);
+
+/* Replace the stored accelerations (subclasses overriding _compute_accelerations,
+ * sensitivity_test.py:61-76: the override's tensor becomes self.accelerations). */
+int nb_set_accelerations(nb_sim *s, const void *acc, int dtype, int on_device);
+
+/* ---- the hot path -------------------------------------------------------------------- */
+
+/* GalaxySimulation._compute_accelerations (simulation.py:74-118) on the current positions,
+ * including quantize_distance_squared (quantization.py:21-71) and, for INT8/INT4,
+ * quantize_force (quantization.py:130-157).  With nranks > 1 the partial sums over this
+ * rank's source block are all-reduced (RCCL) before force quantisation. */
+int nb_compute_accelerations(nb_sim *s);
+
+/* GalaxySimulation.step (simulation.py:120-143), `nsteps` times, entirely on the device. */
+int nb_step(nb_sim *s, int32_t nsteps);
+
+/* The two halves of step() around an externally supplied force (override path):
+ * nb_kick_drift: v += a*(dt/2); x += v*dt   (simulation.py:132,135)
+ * nb_kick:       v += a*(dt/2)              (simulation.py:141)                          */
+int nb_kick_drift(nb_sim *s);
+int nb_kick(nb_sim *s);
+
+/* get_kinetic_energy / get_potential_energy (simulation.py:170-192); either may be NULL. */
+int nb_energy(nb_sim *s, double *kinetic, double *potential);
+
+/* ---- precision-hook introspection ---------------------------------------------------- */
+
+/* Grid-mode internals of the LAST force evaluation: info[0..3] = lmin, lmax (log-grid of
+ * quantization.py:109-113), fmin, fmax (linear force grid, quantization.py:78-79);
+ * info[4] = max r^2 over all pairs.  If d2bins != NULL (host, n*n int16, row i / column j)
+ * the distance-bin index of every pair is recomputed on the device with the same tables the
+ * force kernel used; fbins (host, n*dim int16) likewise for the force bins of INT8/INT4.
+ * -1 marks "degenerate grid: value passed through" (quantization.py:115-116 / :81-82). */
+int nb_quant_debug(nb_sim *s, double info[5], int16_t *d2bins, int16_t *fbins);
+
+/* ---- tensor-level hooks (quantization.py module functions used by override subclasses) -- */
+
+/* quantize_distance_squared(dist_sq, mode, custom_levels, min_dist_sq) quantization.py:21.
+ * in/out: `count` elements of `dtype` (NB_F32 or NB_F64); *out_dtype receives the result
+ * dtype (FLOAT64 -> f64, FLOAT32/BF16/F16 -> f32, grid modes -> input dtype). */
+int nb_quantize_distance_squared(int device, const void *in, void *out, int64_t count, int dtype,
+                                 int mode, int levels, double min_dist_sq, int on_device,
+                                 int32_t *out_dtype);
+/* quantize_force(force, mode, custom_levels) quantization.py:130 */
+int nb_quantize_force(int device, const void *in, void *out, int64_t count, int dtype,
+                      int mode, int levels, int on_device, int32_t *out_dtype);
+/* _grid_quantize(tensor, levels) quantization.py:74 */
+int nb_grid_quantize(int device, const void *in, void *out, int64_t count, int dtype,
+                     int levels, int on_device);
+/* _grid_quantize_safe(tensor, levels, min_val) quantization.py:91 */
+int nb_grid_quantize_safe(int device, const void *in, void *out, int64_t count, int dtype,
+                          int levels, double min_val, int on_device);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------------------------------- */
+
+/* Rank 0 obtains an id (ncclGetUniqueId) and ships the bytes to the other ranks by any
+ * means (torch.distributed store / gloo broadcast); every rank then calls nb_comm_init. */
+int nb_comm_unique_id(void *id_out, int32_t *id_bytes /* in: capacity, out: size */);
+int nb_comm_init(nb_sim *s, const void *id, int32_t id_bytes);
+
+/* ---- measurement --------------------------------------------------------------------- */
+
+/* With NB_FLAG_PROFILE: HIP-event time of the force kernel launches since the last call
+ * (events recorded on the handle's own stream).  total_ms / launches = average duration. */
+int nb_kernel_time(nb_sim *s, double *total_ms, int32_t *launches);
+/* Block until all work queued on the handle's stream has finished. */
+int nb_synchronize(nb_sim *s);
+
+/* ---- misc ---------------------------------------------------------------------------- */
+int nb_device_count(int32_t *count);
+int nb_abi_version(void);
+const char *nb_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_AMD_H */

@@ -1,0 +1,732 @@
+// nb_api.cpp -- C-ABI of the MI355X N-body engine (include/nbody_amd.h).
+//
+// Host-side orchestration only: owns the per-handle device state, decides the launch geometry,
+// tracks the reference's dtype state machine and sequences the kernels
+// of one force evaluation / leapfrog step on the handle's own HIP stream.  No arithmetic of
+// the hot path runs on the host; without a HIP device every entry point fails.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nb_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? NB_ERR_OOM : NB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                               \
+    } while (0)
+
+inline int promote(int a, int b)
+{
+    if (a == b) return a;
+    if (a == NB_F64 || b == NB_F64) return NB_F64;
+    return NB_F32;
+}
+inline size_t dt_size(int dt) { return dt == NB_F64 ? 8 : (dt == NB_F32 ? 4 : 2); }
+
+// ---- RCCL, resolved lazily so single-GPU use never loads it ---------------------------------
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.lib) return NB_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(NB_ERR_COMM, "cannot load librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(NB_ERR_COMM, "librccl is missing expected symbols");
+    g_rccl.lib = h;
+    return NB_OK;
+}
+
+#define NCCLCHK(expr)                                                                             \
+    do {                                                                                          \
+        ncclResult_t r_ = (expr);                                                                 \
+        if (r_ != ncclSuccess)                                                                    \
+            return fail(NB_ERR_COMM, "%s failed: %s", #expr,                                      \
+                        g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?");                 \
+    } while (0)
+
+constexpr int PROF_RING = 256;
+
+}  // namespace
+
+struct nb_sim {
+    nb_config cfg{};
+    hipStream_t stream = nullptr;
+    bool have_storage = false;
+    bool is_f64 = false;                 // storage / accumulation type of the state buffers
+    int logical[4] = {NB_F32, NB_F32, NB_F32, NB_F32};   // pos, vel, mass, acc as Python sees them
+    bool have_pos = false, have_vel = false, have_mass = false, have_acc = false;
+    void *pos = nullptr, *vel = nullptr, *mass = nullptr, *acc = nullptr;
+    double *partial = nullptr;           // nchunks slabs of n*dim fp64 partial sums
+    void *staging = nullptr;             // n*dim*8 bytes, for dtype conversion on upload / download
+    GridTables *tab = nullptr;
+    double *scratch = nullptr;           // per-block energy partials
+    size_t scratch_elems = 0;
+    double *scalars = nullptr;           // device: [0,1] force min/max, [2] ke, [3] pe
+    int16_t *fbins = nullptr;            // n*dim, INT8/INT4 only
+    ForceGeom geom{};
+    ncclComm_t comm = nullptr;
+    // profiling
+    hipEvent_t ev_start[PROF_RING], ev_stop[PROF_RING];
+    bool prof_init = false;
+    int prof_count = 0;
+    double prof_total_ms = 0.0;
+    int prof_launches = 0;
+};
+
+namespace {
+
+int64_t nd(const nb_sim *s) { return (int64_t)s->cfg.n * s->cfg.dim; }
+
+bool grid_mode(int mode) { return mode >= NB_INT8_SIM; }
+int mode_levels(const nb_config &c)
+{
+    if (c.mode == NB_INT8_SIM) return 256;
+    if (c.mode == NB_INT4_SIM) return 16;
+    return c.levels > 0 ? c.levels : 64;
+}
+bool force_quant_mode(const nb_config &c)
+{
+    return c.mode == NB_INT8_SIM || c.mode == NB_INT4_SIM ||
+           (c.mode == NB_CUSTOM && (c.flags & NB_FLAG_CUSTOM_FORCEQ));
+}
+
+void compute_geometry(nb_sim *s)
+{
+    const int n = s->cfg.n;
+    ForceGeom g{};
+    g.n = n;
+    g.j_begin = (int)((int64_t)s->cfg.rank * n / s->cfg.nranks);
+    g.j_end = (int)((int64_t)(s->cfg.rank + 1) * n / s->cfg.nranks);
+    g.r = 2;
+    if (const char *e = getenv("NB_R")) {           // tuning knob: targets per thread (1, 2 or 4)
+        const int r = atoi(e);
+        if (r == 1 || r == 2 || r == 4) g.r = r;
+    }
+    const int njr = std::max(g.j_end - g.j_begin, 1);
+    const int itiles = (n + NB_BLOCK * g.r - 1) / (NB_BLOCK * g.r);
+    const int max_chunks = (njr + NB_TJ - 1) / NB_TJ;
+    int nch = (1024 + itiles - 1) / itiles;       // aim for >= 4 workgroups per CU
+    nch = std::max(1, std::min(std::min(nch, max_chunks), 64));
+    int chunk = (njr + nch - 1) / nch;
+    chunk = (chunk + NB_TJ - 1) / NB_TJ * NB_TJ;
+    g.chunk_len = chunk;
+    g.nchunks = (njr + chunk - 1) / chunk;
+    s->geom = g;
+}
+
+int ensure_storage(nb_sim *s, bool f64)
+{
+    if (s->have_storage) {
+        if (s->is_f64 != f64)
+            return fail(NB_ERR_UNSUPPORTED, "state storage type cannot change after the first upload "
+                                            "(create a new handle for a different input dtype)");
+        return NB_OK;
+    }
+    HIPCHK(hipSetDevice(s->cfg.device));
+    s->is_f64 = f64;
+    const size_t el = f64 ? 8 : 4;
+    const size_t cnt = (size_t)nd(s);
+    HIPCHK(hipMalloc(&s->pos, cnt * el));
+    HIPCHK(hipMalloc(&s->vel, cnt * el));
+    HIPCHK(hipMalloc(&s->acc, cnt * el));
+    HIPCHK(hipMalloc(&s->mass, (size_t)s->cfg.n * el));
+    HIPCHK(hipMalloc(&s->staging, cnt * 8));
+    HIPCHK(hipMalloc((void **)&s->partial, (size_t)s->geom.nchunks * cnt * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&s->tab, sizeof(GridTables)));
+    HIPCHK(hipMemsetAsync(s->tab, 0, sizeof(GridTables), s->stream));
+    const size_t pe_blocks = (size_t)((s->cfg.n + NB_BLOCK - 1) / NB_BLOCK) * s->geom.nchunks;
+    s->scratch_elems = std::max<size_t>(pe_blocks, 1024);
+    HIPCHK(hipMalloc((void **)&s->scratch, s->scratch_elems * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&s->scalars, 8 * sizeof(double)));
+    HIPCHK(hipMemsetAsync(s->scalars, 0, 8 * sizeof(double), s->stream));
+    if (force_quant_mode(s->cfg)) HIPCHK(hipMalloc((void **)&s->fbins, cnt * sizeof(int16_t)));
+    HIPCHK(hipMemsetAsync(s->acc, 0, cnt * el, s->stream));
+    s->have_storage = true;
+    return NB_OK;
+}
+
+// copy `count` elements of dtype `dt` from a caller buffer into state storage (with conversion)
+int upload(nb_sim *s, const void *src, int dt, int on_device, void *dst, int64_t count)
+{
+    const int sdt = s->is_f64 ? NB_F64 : NB_F32;
+    const size_t bytes = (size_t)count * dt_size(dt);
+    if (dt == sdt) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                              s->stream));
+        if (!on_device) HIPCHK(hipStreamSynchronize(s->stream));   // caller may reuse its buffer
+        return NB_OK;
+    }
+    const void *dsrc = src;
+    if (!on_device) {
+        HIPCHK(hipMemcpyAsync(s->staging, src, bytes, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        dsrc = s->staging;
+    }
+    HIPCHK(nb_launch_convert(dsrc, dt, dst, sdt, count, s->stream));
+    return NB_OK;
+}
+
+int download(nb_sim *s, const void *src, int logical_dt, void *dst, int on_device, int64_t count)
+{
+    const int sdt = s->is_f64 ? NB_F64 : NB_F32;
+    const size_t bytes = (size_t)count * dt_size(logical_dt);
+    if (logical_dt == sdt) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                              s->stream));
+        return NB_OK;
+    }
+    if (on_device) {
+        HIPCHK(nb_launch_convert(src, sdt, dst, logical_dt, count, s->stream));
+        return NB_OK;
+    }
+    HIPCHK(nb_launch_convert(src, sdt, s->staging, logical_dt, count, s->stream));
+    HIPCHK(hipMemcpyAsync(dst, s->staging, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));   // staging is reused by the next array
+    return NB_OK;
+}
+
+int acc_logical_dtype(const nb_sim *s)
+{
+    // promote(promote(Q, M), P) with Q = hook output dtype (quantization.py:43-71)
+    int q = s->logical[0];
+    if (s->cfg.mode == NB_FLOAT64) q = NB_F64;
+    else if (s->cfg.mode <= NB_FLOAT16) q = NB_F32;
+    return promote(promote(promote(q, s->logical[2]), NB_F32), s->logical[0]);
+}
+
+int prof_begin(nb_sim *s, int *slot)
+{
+    *slot = -1;
+    if (!(s->cfg.flags & NB_FLAG_PROFILE)) return NB_OK;
+    if (!s->prof_init) {
+        for (int i = 0; i < PROF_RING; ++i) {
+            HIPCHK(hipEventCreate(&s->ev_start[i]));
+            HIPCHK(hipEventCreate(&s->ev_stop[i]));
+        }
+        s->prof_init = true;
+    }
+    if (s->prof_count == PROF_RING) {   // drain
+        HIPCHK(hipStreamSynchronize(s->stream));
+        for (int i = 0; i < PROF_RING; ++i) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, s->ev_start[i], s->ev_stop[i]));
+            s->prof_total_ms += ms;
+        }
+        s->prof_launches += PROF_RING;
+        s->prof_count = 0;
+    }
+    *slot = s->prof_count++;
+    HIPCHK(hipEventRecord(s->ev_start[*slot], s->stream));
+    return NB_OK;
+}
+int prof_end(nb_sim *s, int slot)
+{
+    if (slot >= 0) HIPCHK(hipEventRecord(s->ev_stop[slot], s->stream));
+    return NB_OK;
+}
+
+// one evaluation of simulation.py:74-118; optionally followed by the closing half kick (:141)
+int force_eval(nb_sim *s, bool do_kick)
+{
+    if (!s->have_pos || !s->have_mass) return fail(NB_ERR_INVALID, "positions and masses must be set first");
+    const nb_config &c = s->cfg;
+    const int64_t cnt = nd(s);
+    const double half_dt = c.dt / 2;
+    const bool fq = force_quant_mode(c) && !((c.flags & NB_FLAG_NO_COMM) && c.nranks > 1);
+    const bool no_comm = (c.flags & NB_FLAG_NO_COMM) != 0;
+    const bool multi = c.nranks > 1 && !no_comm;
+    if (multi && !s->comm) return fail(NB_ERR_COMM, "nranks > 1 but nb_comm_init was not called");
+    if (no_comm && c.nranks > 1 && do_kick) return fail(NB_ERR_INVALID, "NB_FLAG_NO_COMM handles cannot step");
+    int slot;
+
+    if (s->is_f64) {
+        if (c.mode != NB_FLOAT64)
+            return fail(NB_ERR_UNSUPPORTED, "fp64 state with a non-FLOAT64 precision mode is not implemented yet");
+        const int pa_f32 = (s->logical[0] == NB_F32);
+        if (int rc = prof_begin(s, &slot)) return rc;
+        HIPCHK(nb_launch_force_f64((const double *)s->pos, (const double *)s->mass, s->partial, s->geom, c.dim,
+                                   pa_f32, c.G, c.softening_sq, s->stream));
+        if (int rc = prof_end(s, slot)) return rc;
+    } else {
+        int hook = HOOK_NONE;
+        if (c.mode == NB_BFLOAT16) hook = HOOK_BF16;
+        else if (c.mode == NB_FLOAT16) hook = HOOK_F16;
+        else if (grid_mode(c.mode)) hook = HOOK_GRID;
+        const float eps2 = (float)c.softening_sq;
+        if (hook == HOOK_GRID) {
+            const int L = mode_levels(c);
+            if (L > NB_MAX_LUT || L < 2)
+                return fail(NB_ERR_UNSUPPORTED, "grid levels must be in [2, %d] on the fused path (got %d)",
+                            NB_MAX_LUT, L);
+            HIPCHK(hipMemsetAsync(&s->tab->r2max_bits, 0, sizeof(unsigned int), s->stream));
+            ForceGeom gmax = s->geom;
+            if (no_comm && c.nranks > 1) {   // a comm-less shard scans every source itself
+                gmax.j_begin = 0;
+                gmax.j_end = c.n;
+                gmax.nchunks = (c.n + gmax.chunk_len - 1) / gmax.chunk_len;
+            }
+            HIPCHK(nb_launch_r2max((const float *)s->pos, gmax, c.dim, eps2, s->tab, s->stream));
+            if (multi)   // NB_FLAG_NO_COMM shards see only their own block's maximum
+                NCCLCHK(g_rccl.AllReduce(&s->tab->r2max_bits, &s->tab->r2max_bits, 1, ncclUint32, ncclMax, s->comm,
+                                         s->stream));
+            HIPCHK(nb_launch_grid_tables(s->tab, L, (float)c.G, eps2, 0.01f, s->stream));
+        }
+        if (int rc = prof_begin(s, &slot)) return rc;
+        HIPCHK(nb_launch_force_f32((const float *)s->pos, (const float *)s->mass, s->partial, s->geom, c.dim, hook,
+                                   (float)c.G, eps2, s->tab, s->stream));
+        if (int rc = prof_end(s, slot)) return rc;
+    }
+
+    const bool fuse_kick = do_kick && !multi && !fq;
+    HIPCHK(nb_launch_reduce(s->partial, s->geom.nchunks, cnt, s->acc, s->is_f64, s->vel, half_dt, fuse_kick,
+                            s->stream));
+    if (multi)
+        NCCLCHK(g_rccl.AllReduce(s->acc, s->acc, (size_t)cnt, s->is_f64 ? ncclDouble : ncclFloat, ncclSum, s->comm,
+                                 s->stream));
+    if (fq) {
+        HIPCHK(nb_launch_minmax_generic(s->acc, 0, cnt, 0, 0.0, s->scalars, s->stream));
+        HIPCHK(nb_launch_force_quant_bins((const float *)s->acc, (float *)s->acc, cnt, mode_levels(c), s->scalars,
+                                          s->fbins, s->stream));
+    }
+    if (do_kick && !fuse_kick) HIPCHK(nb_launch_axpy(s->vel, s->acc, half_dt, cnt, s->is_f64, s->stream));
+    s->logical[3] = acc_logical_dtype(s);
+    s->have_acc = true;
+    return NB_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(dev); }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+int nb_abi_version(void) { return NB_ABI_VERSION; }
+const char *nb_last_error(void) { return g_err.c_str(); }
+
+int nb_device_count(int32_t *count)
+{
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; return fail(NB_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = c;
+    return NB_OK;
+}
+
+int nb_create(nb_sim **out, const nb_config *cfg)
+{
+    if (!out || !cfg) return fail(NB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->n < 1) return fail(NB_ERR_INVALID, "n must be >= 1 (got %d)", cfg->n);
+    if (cfg->dim != 2 && cfg->dim != 3) return fail(NB_ERR_INVALID, "dim must be 2 or 3 (got %d)", cfg->dim);
+    if (cfg->mode < NB_FLOAT64 || cfg->mode > NB_CUSTOM) return fail(NB_ERR_INVALID, "bad precision mode %d", cfg->mode);
+    if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks)
+        return fail(NB_ERR_INVALID, "bad shard %d of %d", cfg->rank, cfg->nranks);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(NB_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(NB_ERR_NO_DEVICE, "device %d out of range [0,%d)", cfg->device, ndev);
+    nb_sim *s = new nb_sim();
+    s->cfg = *cfg;
+    DeviceGuard guard(cfg->device);
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete s;
+        return fail(NB_ERR_HIP, "hipStreamCreate failed");
+    }
+    compute_geometry(s);
+    *out = s;
+    return NB_OK;
+}
+
+int nb_destroy(nb_sim *s)
+{
+    if (!s) return NB_OK;
+    DeviceGuard guard(s->cfg.device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
+    for (void *p : {s->pos, s->vel, s->mass, s->acc, (void *)s->partial, s->staging, (void *)s->tab,
+                    (void *)s->scratch, (void *)s->scalars, (void *)s->fbins})
+        if (p) (void)hipFree(p);
+    if (s->prof_init)
+        for (int i = 0; i < PROF_RING; ++i) { (void)hipEventDestroy(s->ev_start[i]); (void)hipEventDestroy(s->ev_stop[i]); }
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return NB_OK;
+}
+
+int nb_set_params(nb_sim *s, double G, double softening_sq, double dt)
+{
+    if (!s) return fail(NB_ERR_INVALID, "null handle");
+    s->cfg.G = G;
+    s->cfg.softening_sq = softening_sq;
+    s->cfg.dt = dt;
+    return NB_OK;
+}
+
+int nb_set_state(nb_sim *s, const void *pos, const void *vel, const void *mass, int dtype, int on_device)
+{
+    if (!s) return fail(NB_ERR_INVALID, "null handle");
+    if (dtype != NB_F32 && dtype != NB_F64)
+        return fail(NB_ERR_UNSUPPORTED, "state dtype %d: only float32 and float64 state is implemented", dtype);
+    DeviceGuard guard(s->cfg.device);
+    const bool want_f64 = (s->cfg.mode == NB_FLOAT64) || dtype == NB_F64;
+    if (dtype == NB_F64 && s->cfg.mode != NB_FLOAT64)
+        return fail(NB_ERR_UNSUPPORTED, "fp64 state with a non-FLOAT64 precision mode is not implemented yet");
+    if (int rc = ensure_storage(s, s->have_storage ? s->is_f64 : want_f64)) return rc;
+    if (dtype == NB_F64 && !s->is_f64) return fail(NB_ERR_UNSUPPORTED, "cannot upload fp64 data into fp32 state");
+    if (pos) { if (int rc = upload(s, pos, dtype, on_device, s->pos, nd(s))) return rc; s->logical[0] = dtype; s->have_pos = true; }
+    if (vel) { if (int rc = upload(s, vel, dtype, on_device, s->vel, nd(s))) return rc; s->logical[1] = dtype; s->have_vel = true; }
+    if (mass) { if (int rc = upload(s, mass, dtype, on_device, s->mass, s->cfg.n)) return rc; s->logical[2] = dtype; s->have_mass = true; }
+    return NB_OK;
+}
+
+int nb_set_accelerations(nb_sim *s, const void *acc, int dtype, int on_device)
+{
+    if (!s || !acc) return fail(NB_ERR_INVALID, "null argument");
+    if (!s->have_storage) return fail(NB_ERR_INVALID, "set the state first");
+    if (dtype != NB_F32 && dtype != NB_F64) return fail(NB_ERR_UNSUPPORTED, "acceleration dtype %d", dtype);
+    if (dtype == NB_F64 && !s->is_f64) return fail(NB_ERR_UNSUPPORTED, "fp64 accelerations on fp32 state");
+    DeviceGuard guard(s->cfg.device);
+    if (int rc = upload(s, acc, dtype, on_device, s->acc, nd(s))) return rc;
+    s->logical[3] = dtype;
+    s->have_acc = true;
+    return NB_OK;
+}
+
+int nb_state_dtypes(nb_sim *s, int32_t dtypes[4])
+{
+    if (!s || !dtypes) return fail(NB_ERR_INVALID, "null argument");
+    for (int i = 0; i < 4; ++i) dtypes[i] = s->logical[i];
+    return NB_OK;
+}
+
+int nb_get_state(nb_sim *s, void *pos, void *vel, void *acc, void *mass, int on_device)
+{
+    if (!s) return fail(NB_ERR_INVALID, "null handle");
+    if (!s->have_storage) return fail(NB_ERR_INVALID, "no state uploaded yet");
+    DeviceGuard guard(s->cfg.device);
+    if (pos) if (int rc = download(s, s->pos, s->logical[0], pos, on_device, nd(s))) return rc;
+    if (vel) if (int rc = download(s, s->vel, s->logical[1], vel, on_device, nd(s))) return rc;
+    if (acc) if (int rc = download(s, s->acc, s->logical[3], acc, on_device, nd(s))) return rc;
+    if (mass) if (int rc = download(s, s->mass, s->logical[2], mass, on_device, s->cfg.n)) return rc;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return NB_OK;
+}
+
+int nb_compute_accelerations(nb_sim *s)
+{
+    if (!s) return fail(NB_ERR_INVALID, "null handle");
+    DeviceGuard guard(s->cfg.device);
+    return force_eval(s, false);
+}
+
+int nb_kick_drift(nb_sim *s)
+{
+    if (!s) return fail(NB_ERR_INVALID, "null handle");
+    if (!s->have_vel || !s->have_pos || !s->have_acc) return fail(NB_ERR_INVALID, "state incomplete");
+    DeviceGuard guard(s->cfg.device);
+    HIPCHK(nb_launch_kick_drift(s->pos, s->vel, s->acc, s->cfg.dt / 2, s->cfg.dt, nd(s), s->is_f64, s->stream));
+    s->logical[1] = promote(s->logical[1], s->logical[3]);
+    s->logical[0] = promote(s->logical[0], s->logical[1]);
+    return NB_OK;
+}
+
+int nb_kick(nb_sim *s)
+{
+    if (!s) return fail(NB_ERR_INVALID, "null handle");
+    if (!s->have_vel || !s->have_acc) return fail(NB_ERR_INVALID, "state incomplete");
+    DeviceGuard guard(s->cfg.device);
+    HIPCHK(nb_launch_axpy(s->vel, s->acc, s->cfg.dt / 2, nd(s), s->is_f64, s->stream));
+    s->logical[1] = promote(s->logical[1], s->logical[3]);
+    return NB_OK;
+}
+
+int nb_step(nb_sim *s, int32_t nsteps)
+{
+    if (!s) return fail(NB_ERR_INVALID, "null handle");
+    if (!s->have_vel || !s->have_pos || !s->have_mass) return fail(NB_ERR_INVALID, "state incomplete");
+    if (!s->have_acc) return fail(NB_ERR_INVALID, "no accelerations yet: call nb_compute_accelerations first");
+    DeviceGuard guard(s->cfg.device);
+    for (int t = 0; t < nsteps; ++t) {
+        HIPCHK(nb_launch_kick_drift(s->pos, s->vel, s->acc, s->cfg.dt / 2, s->cfg.dt, nd(s), s->is_f64, s->stream));
+        s->logical[1] = promote(s->logical[1], s->logical[3]);
+        s->logical[0] = promote(s->logical[0], s->logical[1]);
+        if (int rc = force_eval(s, true)) return rc;
+        s->logical[1] = promote(s->logical[1], s->logical[3]);
+    }
+    return NB_OK;
+}
+
+int nb_energy(nb_sim *s, double *kinetic, double *potential)
+{
+    if (!s) return fail(NB_ERR_INVALID, "null handle");
+    DeviceGuard guard(s->cfg.device);
+    const nb_config &c = s->cfg;
+    double host[2] = {0, 0};
+    if (kinetic) {
+        if (!s->have_vel || !s->have_mass) return fail(NB_ERR_INVALID, "velocities/masses not set");
+        HIPCHK(nb_launch_kinetic(s->vel, s->mass, c.n, c.dim, s->is_f64, s->logical[1] != NB_F64, s->scratch,
+                                 s->scalars + 2, s->stream));
+    }
+    if (potential) {
+        if (!s->have_pos || !s->have_mass) return fail(NB_ERR_INVALID, "positions/masses not set");
+        HIPCHK(nb_launch_potential(s->pos, s->mass, s->geom, c.dim, s->is_f64, s->logical[0] != NB_F64,
+                                   c.softening_sq, s->scratch, s->scalars + 3, s->stream));
+        if (c.nranks > 1 && !(c.flags & NB_FLAG_NO_COMM)) {
+            if (!s->comm) return fail(NB_ERR_COMM, "nranks > 1 but nb_comm_init was not called");
+            NCCLCHK(g_rccl.AllReduce(s->scalars + 3, s->scalars + 3, 1, ncclDouble, ncclSum, s->comm, s->stream));
+        }
+    }
+    HIPCHK(hipMemcpyAsync(host, s->scalars + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (kinetic) {
+        // ke = 0.5 * (masses * v_sq).sum() in the promoted dtype of (velocities, masses)
+        if (promote(s->logical[1], s->logical[2]) == NB_F64) *kinetic = 0.5 * host[0];
+        else *kinetic = (double)(0.5f * (float)host[0]);
+    }
+    if (potential) {
+        if (promote(s->logical[0], s->logical[2]) == NB_F64) *potential = -c.G * host[1];
+        else *potential = (double)((float)(-c.G) * (float)host[1]);
+    }
+    return NB_OK;
+}
+
+int nb_quant_debug(nb_sim *s, double info[5], int16_t *d2bins, int16_t *fbins)
+{
+    if (!s) return fail(NB_ERR_INVALID, "null handle");
+    if (!s->have_storage || s->is_f64 || !grid_mode(s->cfg.mode))
+        return fail(NB_ERR_INVALID, "quant debug is only defined for the grid modes");
+    DeviceGuard guard(s->cfg.device);
+    GridTables h;
+    double mnmx[2];
+    HIPCHK(hipMemcpyAsync(&h, s->tab, sizeof h, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(mnmx, s->scalars, sizeof mnmx, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (info) { info[0] = h.lmin; info[1] = h.lmax; info[2] = mnmx[0]; info[3] = mnmx[1]; info[4] = h.r2max; }
+    const int n = s->cfg.n;
+    if (d2bins) {
+        int16_t *dev = nullptr;
+        HIPCHK(hipMalloc((void **)&dev, (size_t)n * n * sizeof(int16_t)));
+        hipError_t e = nb_launch_d2bins((const float *)s->pos, n, s->cfg.dim, (float)s->cfg.softening_sq, s->tab, dev,
+                                        s->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d2bins, dev, (size_t)n * n * sizeof(int16_t), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        (void)hipFree(dev);
+        HIPCHK(e);
+    }
+    if (fbins) {
+        if (!s->fbins) return fail(NB_ERR_INVALID, "this mode does not quantise forces");
+        HIPCHK(hipMemcpyAsync(fbins, s->fbins, (size_t)nd(s) * sizeof(int16_t), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    return NB_OK;
+}
+
+}  // extern "C"
+
+// ---- tensor-level hooks ----------------------------------------------------------------------
+namespace {
+struct TempBuf {
+    void *p = nullptr;
+    ~TempBuf() { if (p) (void)hipFree(p); }
+};
+
+// run `body(d_in, d_out, d_scal)` with device views of the caller's buffers
+template <typename F>
+int with_device_buffers(int device, const void *in, void *out, size_t in_bytes, size_t out_bytes, int on_device, F &&body)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(NB_ERR_NO_DEVICE, "no HIP device available; this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(NB_ERR_NO_DEVICE, "device %d out of range", device);
+    DeviceGuard guard(device);
+    TempBuf tin, tout, tscal;
+    HIPCHK(hipMalloc(&tscal.p, 2 * sizeof(double)));
+    const void *din = in;
+    void *dout = out;
+    if (!on_device) {
+        HIPCHK(hipMalloc(&tin.p, std::max<size_t>(in_bytes, 8)));
+        HIPCHK(hipMalloc(&tout.p, std::max<size_t>(out_bytes, 8)));
+        HIPCHK(hipMemcpy(tin.p, in, in_bytes, hipMemcpyHostToDevice));
+        din = tin.p;
+        dout = tout.p;
+    }
+    if (int rc = body(din, dout, (double *)tscal.p)) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    if (!on_device) HIPCHK(hipMemcpy(out, tout.p, out_bytes, hipMemcpyDeviceToHost));
+    return NB_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int nb_grid_quantize(int device, const void *in, void *out, int64_t count, int dtype, int levels, int on_device)
+{
+    if (dtype != NB_F32 && dtype != NB_F64) return fail(NB_ERR_UNSUPPORTED, "dtype %d", dtype);
+    if (count < 1 || levels < 2) return fail(NB_ERR_INVALID, "count >= 1 and levels >= 2 required");
+    const size_t bytes = (size_t)count * dt_size(dtype);
+    return with_device_buffers(device, in, out, bytes, bytes, on_device, [&](const void *din, void *dout, double *sc) {
+        HIPCHK(nb_launch_minmax_generic(din, dtype == NB_F64, count, 0, 0.0, sc, nullptr));
+        HIPCHK(nb_launch_grid_quantize(din, dout, dtype == NB_F64, count, levels, sc, nullptr));
+        return (int)NB_OK;
+    });
+}
+
+int nb_grid_quantize_safe(int device, const void *in, void *out, int64_t count, int dtype, int levels, double min_val,
+                          int on_device)
+{
+    if (dtype != NB_F32 && dtype != NB_F64) return fail(NB_ERR_UNSUPPORTED, "dtype %d", dtype);
+    if (count < 1 || levels < 2) return fail(NB_ERR_INVALID, "count >= 1 and levels >= 2 required");
+    const size_t bytes = (size_t)count * dt_size(dtype);
+    return with_device_buffers(device, in, out, bytes, bytes, on_device, [&](const void *din, void *dout, double *sc) {
+        HIPCHK(nb_launch_minmax_generic(din, dtype == NB_F64, count, 1, min_val, sc, nullptr));
+        HIPCHK(nb_launch_grid_quantize_safe(din, dout, dtype == NB_F64, count, levels, min_val, sc, nullptr));
+        return (int)NB_OK;
+    });
+}
+
+int nb_quantize_distance_squared(int device, const void *in, void *out, int64_t count, int dtype, int mode, int levels,
+                                 double min_dist_sq, int on_device, int32_t *out_dtype)
+{
+    if (dtype != NB_F32 && dtype != NB_F64) return fail(NB_ERR_UNSUPPORTED, "dtype %d", dtype);
+    if (mode < NB_FLOAT64 || mode > NB_CUSTOM) return fail(NB_ERR_INVALID, "bad mode %d", mode);
+    if (mode >= NB_INT8_SIM) {
+        const int L = mode == NB_INT8_SIM ? 256 : (mode == NB_INT4_SIM ? 16 : (levels > 0 ? levels : 64));
+        if (out_dtype) *out_dtype = dtype;
+        return nb_grid_quantize_safe(device, in, out, count, dtype, L, min_dist_sq, on_device);
+    }
+    const int odt = (mode == NB_FLOAT64) ? NB_F64 : NB_F32;
+    if (out_dtype) *out_dtype = odt;
+    return with_device_buffers(device, in, out, (size_t)count * dt_size(dtype), (size_t)count * dt_size(odt), on_device,
+                               [&](const void *din, void *dout, double *) {
+                                   HIPCHK(nb_launch_cast_hook(din, dtype, dout, mode, count, nullptr));
+                                   return (int)NB_OK;
+                               });
+}
+
+int nb_quantize_force(int device, const void *in, void *out, int64_t count, int dtype, int mode, int levels, int on_device,
+                      int32_t *out_dtype)
+{
+    if (dtype != NB_F32 && dtype != NB_F64) return fail(NB_ERR_UNSUPPORTED, "dtype %d", dtype);
+    if (mode < NB_FLOAT64 || mode > NB_CUSTOM) return fail(NB_ERR_INVALID, "bad mode %d", mode);
+    if (mode >= NB_INT8_SIM) {
+        const int L = mode == NB_INT8_SIM ? 256 : (mode == NB_INT4_SIM ? 16 : (levels > 0 ? levels : 64));
+        if (out_dtype) *out_dtype = dtype;
+        return nb_grid_quantize(device, in, out, count, dtype, L, on_device);
+    }
+    // FLOAT64 / FLOAT32: identity; BF16 / F16: round trip (quantization.py:139-146)
+    const bool identity = (mode == NB_FLOAT64 || mode == NB_FLOAT32);
+    const int odt = identity ? dtype : NB_F32;
+    if (out_dtype) *out_dtype = odt;
+    const int cast_mode = identity ? (dtype == NB_F64 ? NB_FLOAT64 : NB_FLOAT32) : mode;
+    return with_device_buffers(device, in, out, (size_t)count * dt_size(dtype), (size_t)count * dt_size(odt), on_device,
+                               [&](const void *din, void *dout, double *) {
+                                   HIPCHK(nb_launch_cast_hook(din, dtype, dout, cast_mode, count, nullptr));
+                                   return (int)NB_OK;
+                               });
+}
+
+// ---- multi-GPU -------------------------------------------------------------------------------
+int nb_comm_unique_id(void *id_out, int32_t *id_bytes)
+{
+    if (!id_out || !id_bytes) return fail(NB_ERR_INVALID, "null argument");
+    if (*id_bytes < (int32_t)sizeof(ncclUniqueId)) return fail(NB_ERR_INVALID, "id buffer too small (need %zu)", sizeof(ncclUniqueId));
+    if (int rc = load_rccl()) return rc;
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    *id_bytes = (int32_t)sizeof id;
+    return NB_OK;
+}
+
+int nb_comm_init(nb_sim *s, const void *id, int32_t id_bytes)
+{
+    if (!s || !id) return fail(NB_ERR_INVALID, "null argument");
+    if (id_bytes != (int32_t)sizeof(ncclUniqueId)) return fail(NB_ERR_INVALID, "bad id size %d", id_bytes);
+    if (int rc = load_rccl()) return rc;
+    DeviceGuard guard(s->cfg.device);
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    NCCLCHK(g_rccl.CommInitRank(&s->comm, s->cfg.nranks, uid, s->cfg.rank));
+    return NB_OK;
+}
+
+// ---- measurement -----------------------------------------------------------------------------
+int nb_kernel_time(nb_sim *s, double *total_ms, int32_t *launches)
+{
+    if (!s) return fail(NB_ERR_INVALID, "null handle");
+    DeviceGuard guard(s->cfg.device);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < s->prof_count; ++i) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, s->ev_start[i], s->ev_stop[i]));
+        s->prof_total_ms += ms;
+    }
+    s->prof_launches += s->prof_count;
+    s->prof_count = 0;
+    if (total_ms) *total_ms = s->prof_total_ms;
+    if (launches) *launches = s->prof_launches;
+    s->prof_total_ms = 0;
+    s->prof_launches = 0;
+    return NB_OK;
+}
+
+int nb_synchronize(nb_sim *s)
+{
+    if (!s) return fail(NB_ERR_INVALID, "null handle");
+    DeviceGuard guard(s->cfg.device);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return NB_OK;
+}
+
+}  // extern "C"

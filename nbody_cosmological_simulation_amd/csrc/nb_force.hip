@@ -1,0 +1,516 @@
+// nb_force.hip -- all-pairs softened-gravity kernels for gfx950 (MI355X, CDNA4).
+//
+// Replaces GalaxySimulation._compute_accelerations (reference simulation.py:74-118) and the
+// per-pair part of quantize_distance_squared (quantization.py:21-71).
+//
+// Decomposition (DESIGN.md "force kernel"):
+//   grid  = (target tiles) x (source chunks); block = 256 threads = 4 wavefronts of 64.
+//   Each thread keeps R targets in registers; the block walks its source chunk in tiles of
+//   NB_TJ particles staged in LDS with one coalesced load per thread; the inner loop reads the
+//   tile with wave-uniform (broadcast, conflict-free) ds_reads.
+//   Every (tile, chunk) block writes an fp64 partial sum per target to its own slab;
+//   reduce_kernel (nb_misc.hip) adds the slabs in fixed order -> run-to-run bit reproducible,
+//   no atomics.
+//   The path is VALU-bound (arithmetic intensity ~0.135*N flop/B), so the
+//   inner loop is written for minimum instruction count: one v_rsq + a fused second-order
+//   correction instead of sqrt/div/pow, no self-interaction mask (d == 0 kills the diagonal
+//   term exactly as the reference's (1 - eye) multiply does, NaN cases included).
+#include "nb_internal.h"
+
+#include <hip/hip_fp16.h>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// q^(-3/2) kernels
+// ------------------------------------------------------------------------------------------
+
+// fp64:  returns gm * q^(-3/2).  y0 = v_rsq_f64(q) (about 2^-26 relative), then with
+// e = 1 - q*y0^2 :  q^(-3/2) = y0^3 * (1-e)^(-3/2) = y0^3 * (1 + e*(3/2 + 15/8 e) + O(e^3)).
+// The neglected term is < 2^-70; the result carries ~1.5 ulp of rounding, the same order as the
+// reference's pow -> reciprocal -> *G -> *m chain (simulation.py:97-105).
+__device__ __forceinline__ double inv_r3_f64(double q, double gm)
+{
+    const double y0 = __builtin_amdgcn_rsq(q);
+    const double y02 = y0 * y0;
+    const double e = __builtin_fma(-q, y02, 1.0);
+    const double u = y0 * gm;
+    const double v = u * y02;
+    const double c = __builtin_fma(e, 1.875, 1.5);
+    const double ce = c * e;
+    return __builtin_fma(v, ce, v);
+}
+
+// fp32:  q^(-3/2) from v_rsq_f32 (1 ulp) plus one Newton step, then cubed.
+__device__ __forceinline__ float inv_r3_f32(float q)
+{
+    const float y0 = __builtin_amdgcn_rsqf(q);
+    const float t = q * y0;
+    const float e = __builtin_fmaf(-t, y0, 1.0f);
+    const float y = __builtin_fmaf(0.5f * y0, e, y0);
+    return (y * y) * y;
+}
+
+__device__ __forceinline__ float round_bf16(float x) { return (float)(__bf16)x; }
+__device__ __forceinline__ float round_f16(float x) { return (float)(_Float16)x; }
+
+// r2 exactly as the reference's fp32 tensors produce it: (dx*dx + dy*dy [+ dz*dz]) + eps2, one
+// rounding per operation, no fused multiply-add (simulation.py:86).
+template <int D>
+__device__ __forceinline__ float r2_f32_exact(const float *d, float eps2)
+{
+    float s = __fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1]));
+    if (D == 3) s = __fadd_rn(s, __fmul_rn(d[2], d[2]));
+    return __fadd_rn(s, eps2);
+}
+
+// bin index = number of thresholds <= r2 (branch-free binary search over the LDS table)
+template <int LP>
+__device__ __forceinline__ int grid_bin_lookup(const float *thr, float r2)
+{
+    int k = 0;
+#pragma unroll
+    for (int step = LP / 2; step >= 1; step >>= 1)
+        k += (thr[k + step] <= r2) ? step : 0;
+    return k;
+}
+
+// ------------------------------------------------------------------------------------------
+// fp64 state (FLOAT64 mode).  PA_F32: diff and r2 in fp32 (first evaluation on fp32-typed
+// positions), everything after the hook in fp64.
+// ------------------------------------------------------------------------------------------
+template <int D, int R, bool PA_F32>
+__global__ void __launch_bounds__(NB_BLOCK)
+force_f64_kernel(const double *__restrict__ pos, const double *__restrict__ mass,
+                 double *__restrict__ partial, ForceGeom g, double G, double eps2, float eps2_f)
+{
+    __shared__ double sj[D + 1][NB_TJ];
+
+    const int tid = threadIdx.x;
+    const int ibase = blockIdx.x * (NB_BLOCK * R);
+
+    double xi[R][D];
+    double acc[R][D];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int i = ibase + r * NB_BLOCK + tid;
+        i = i < g.n ? i : g.n - 1;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            xi[r][k] = pos[(size_t)i * D + k];
+            acc[r][k] = 0.0;
+        }
+    }
+
+    const int j_lo = g.j_begin + blockIdx.y * g.chunk_len;
+    const int j_hi = min(j_lo + g.chunk_len, g.j_end);
+
+    for (int jt = j_lo; jt < j_hi; jt += NB_TJ) {
+        {
+            int j = jt + tid;
+            j = j < j_hi ? j : j_hi - 1;
+#pragma unroll
+            for (int k = 0; k < D; ++k) sj[k][tid] = pos[(size_t)j * D + k];
+            sj[D][tid] = G * mass[j];
+        }
+        __syncthreads();
+        const int cnt = min(NB_TJ, j_hi - jt);
+#pragma unroll 4
+        for (int jj = 0; jj < cnt; ++jj) {
+            double xj[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) xj[k] = sj[k][jj];
+            const double gm = sj[D][jj];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double d[D];
+                double q;
+                if (PA_F32) {
+                    float df[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        df[k] = __fsub_rn((float)xj[k], (float)xi[r][k]);
+                        d[k] = (double)df[k];
+                    }
+                    q = (double)r2_f32_exact<D>(df, eps2_f);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) d[k] = xj[k] - xi[r][k];
+                    q = __builtin_fma(d[D - 1], d[D - 1], eps2);
+#pragma unroll
+                    for (int k = D - 2; k >= 0; --k) q = __builtin_fma(d[k], d[k], q);
+                }
+                const double w = inv_r3_f64(q, gm);
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc[r][k] = __builtin_fma(w, d[k], acc[r][k]);
+            }
+        }
+        __syncthreads();
+    }
+
+    double *out = partial + (size_t)blockIdx.y * g.n * D;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = ibase + r * NB_BLOCK + tid;
+        if (i < g.n) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) out[(size_t)i * D + k] = acc[r][k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 state (FLOAT32 / BFLOAT16 / FLOAT16 / INT8 / INT4 / CUSTOM modes)
+// ------------------------------------------------------------------------------------------
+template <int D, int R, int HOOK, int LP>
+__global__ void __launch_bounds__(NB_BLOCK)
+force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
+                 double *__restrict__ partial, ForceGeom g, float G, float eps2,
+                 const GridTables *__restrict__ tab)
+{
+    __shared__ float sj[D + 1][NB_TJ];
+    __shared__ float s_thr[HOOK == HOOK_GRID ? LP : 1];
+    __shared__ float s_lut[HOOK == HOOK_GRID ? LP : 1];
+
+    const int tid = threadIdx.x;
+    const int ibase = blockIdx.x * (NB_BLOCK * R);
+    bool degenerate = false;
+
+    if (HOOK == HOOK_GRID) {
+        for (int k = tid; k < LP; k += NB_BLOCK) {
+            s_thr[k] = (k < tab->levels) ? tab->thr[k] : __builtin_inff();
+            s_lut[k] = (k < tab->levels) ? tab->lut[k] : 0.0f;
+        }
+        degenerate = tab->degenerate != 0;
+    }
+
+    float xi[R][D];
+    double acc[R][D];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int i = ibase + r * NB_BLOCK + tid;
+        i = i < g.n ? i : g.n - 1;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            xi[r][k] = pos[(size_t)i * D + k];
+            acc[r][k] = 0.0;
+        }
+    }
+
+    const int j_lo = g.j_begin + blockIdx.y * g.chunk_len;
+    const int j_hi = min(j_lo + g.chunk_len, g.j_end);
+
+    for (int jt = j_lo; jt < j_hi; jt += NB_TJ) {
+        {
+            int j = jt + tid;
+            j = j < j_hi ? j : j_hi - 1;
+#pragma unroll
+            for (int k = 0; k < D; ++k) sj[k][tid] = pos[(size_t)j * D + k];
+            sj[D][tid] = mass[j];
+        }
+        __syncthreads();
+        const int cnt = min(NB_TJ, j_hi - jt);
+        // fp32 running sums over one tile only; the tile sums are folded into fp64 accumulators
+        // so the error of an N-term fp32 sum stays at the level of torch's cascade summation.
+        float tacc[R][D];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < D; ++k) tacc[r][k] = 0.0f;
+
+#pragma unroll 4
+        for (int jj = 0; jj < cnt; ++jj) {
+            float xj[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) xj[k] = sj[k][jj];
+            const float mj = sj[D][jj];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float d[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) d[k] = __fsub_rn(xj[k], xi[r][k]);
+                const float r2 = r2_f32_exact<D>(d, eps2);
+                float wq;   // (1 / q^1.5) * G   (simulation.py:97-101)
+                if (HOOK == HOOK_GRID) {
+                    if (!degenerate) {
+                        wq = s_lut[grid_bin_lookup<LP>(s_thr, r2)];
+                    } else {
+                        const float q = (r2 < 0.01f) ? 0.01f : r2;     // clamp keeps NaN
+                        wq = inv_r3_f32(q) * G;
+                    }
+                } else {
+                    float q = r2;
+                    if (HOOK == HOOK_BF16) q = round_bf16(r2);
+                    if (HOOK == HOOK_F16) q = round_f16(r2);
+                    wq = inv_r3_f32(q) * G;
+                }
+                const float w = wq * mj;                                // simulation.py:105
+#pragma unroll
+                for (int k = 0; k < D; ++k) tacc[r][k] = __builtin_fmaf(w, d[k], tacc[r][k]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc[r][k] += (double)tacc[r][k];
+        __syncthreads();
+    }
+
+    double *out = partial + (size_t)blockIdx.y * g.n * D;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = ibase + r * NB_BLOCK + tid;
+        if (i < g.n) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) out[(size_t)i * D + k] = acc[r][k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: global max of the fp32 r2 over (all targets) x (this rank's sources).
+// quantization.py:113 needs log(max r2); the minimum is analytic (diagonal).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int r2_order_bits(float v)
+{
+    // r2 >= 0 always, so the IEEE bit pattern orders like an unsigned int; any NaN maps above +inf
+    return (v != v) ? 0x7fc00000u : __float_as_uint(v);
+}
+
+template <int D, int R>
+__global__ void __launch_bounds__(NB_BLOCK)
+r2max_kernel(const float *__restrict__ pos, ForceGeom g, float eps2, GridTables *__restrict__ tab)
+{
+    __shared__ float sj[D][NB_TJ];
+    __shared__ unsigned int s_red[NB_BLOCK / 64];
+    const int tid = threadIdx.x;
+    const int ibase = blockIdx.x * (NB_BLOCK * R);
+
+    float xi[R][D];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int i = ibase + r * NB_BLOCK + tid;
+        i = i < g.n ? i : g.n - 1;
+#pragma unroll
+        for (int k = 0; k < D; ++k) xi[r][k] = pos[(size_t)i * D + k];
+    }
+    const int j_lo = g.j_begin + blockIdx.y * g.chunk_len;
+    const int j_hi = min(j_lo + g.chunk_len, g.j_end);
+
+    unsigned int best = 0;
+    for (int jt = j_lo; jt < j_hi; jt += NB_TJ) {
+        {
+            int j = jt + tid;
+            j = j < j_hi ? j : j_hi - 1;
+#pragma unroll
+            for (int k = 0; k < D; ++k) sj[k][tid] = pos[(size_t)j * D + k];
+        }
+        __syncthreads();
+        const int cnt = min(NB_TJ, j_hi - jt);
+#pragma unroll 8
+        for (int jj = 0; jj < cnt; ++jj) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float d[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) d[k] = __fsub_rn(sj[k][jj], xi[r][k]);
+                best = max(best, r2_order_bits(r2_f32_exact<D>(d, eps2)));
+            }
+        }
+        __syncthreads();
+    }
+    // wavefront (64-lane) shuffle reduction, then one atomic per block
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = max(best, (unsigned int)__shfl_xor((int)best, off, 64));
+    if ((tid & 63) == 0) s_red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int b = s_red[0];
+#pragma unroll
+        for (int w = 1; w < NB_BLOCK / 64; ++w) b = max(b, s_red[w]);
+        atomicMax(&tab->r2max_bits, b);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Grid tables: exact scalar form of _grid_quantize_safe (quantization.py:91-127) evaluated on
+// the device once per force evaluation.  Every stage (clamp, log, -lmin, /range, *(L-1), round)
+// is monotone in r2, so the bin index is a step function of the fp32 r2: thread k finds the
+// smallest fp32 value whose bin is >= k by bisection over bit patterns.  Bit-identical to
+// evaluating the formula per pair, with no log/div/exp in the pair loop.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float logf_cr(float t) { return (float)log((double)t); }
+
+__device__ __forceinline__ float grid_bin_exact(float t, float min_val, float lmin, float range, float lm1)
+{
+    const float ts = (t < min_val) ? min_val : t;
+    const float lt = logf_cr(ts);
+    const float nrm = __fmul_rn(__fdiv_rn(__fsub_rn(lt, lmin), range), lm1);
+    return rintf(nrm);   // half-to-even like torch.round
+}
+
+__global__ void __launch_bounds__(NB_MAX_LUT)
+grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2, float min_val)
+{
+    const int k = threadIdx.x;
+    const float r2max = __uint_as_float(tab->r2max_bits);
+    const float tmin = (eps2 < min_val) ? min_val : eps2;        // diagonal entries: r2 == eps2
+    const float tmax = (r2max < min_val) ? min_val : r2max;
+    const float lmin = logf_cr(tmin);
+    const float lmax = logf_cr(tmax);
+    const float range = __fsub_rn(lmax, lmin);
+    const float lm1 = (float)(levels - 1);
+    const bool degenerate = range < 1e-10f || levels > NB_MAX_LUT;
+
+    if (k < levels) {
+        // value of bin k (quantization.py:121-127) and its force factor (simulation.py:97-101)
+        float v = __fdiv_rn((float)k, lm1);
+        v = __fmul_rn(v, range);
+        v = __fadd_rn(v, lmin);
+        float q = (float)exp((double)v);
+        q = (q < min_val) ? min_val : q;
+        const float p = (float)pow((double)q, 1.5);
+        tab->qval[k] = q;
+        tab->lut[k] = __fmul_rn(__fdiv_rn(1.0f, p), G);
+
+        float thr = -__builtin_inff();
+        if (k > 0 && !degenerate) {
+            if (r2max != r2max) {
+                thr = __builtin_nanf("");
+            } else {
+                unsigned int lo = __float_as_uint(tmin);   // bin(tmin) == 0 < k
+                unsigned int hi = __float_as_uint(tmax);   // bin(tmax) == L-1 >= k
+                while (hi - lo > 1u) {
+                    const unsigned int mid = lo + ((hi - lo) >> 1);
+                    const float b = grid_bin_exact(__uint_as_float(mid), min_val, lmin, range, lm1);
+                    if (b >= (float)k) hi = mid; else lo = mid;
+                }
+                thr = __uint_as_float(hi);
+            }
+        }
+        tab->thr[k] = thr;
+    }
+    if (k == 0) {
+        tab->lmin = lmin;
+        tab->lmax = lmax;
+        tab->range = range;
+        tab->r2max = r2max;
+        tab->degenerate = (range < 1e-10f) ? 1 : 0;
+        tab->levels = levels;
+    }
+}
+
+// debug / parity: bin index of every pair with the tables the force kernel used
+template <int D>
+__global__ void __launch_bounds__(NB_BLOCK)
+d2bins_kernel(const float *__restrict__ pos, int n, float eps2, const GridTables *__restrict__ tab,
+              int16_t *__restrict__ bins)
+{
+    const int j = blockIdx.x * NB_BLOCK + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= n) return;
+    float d[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) d[k] = __fsub_rn(pos[(size_t)j * D + k], pos[(size_t)i * D + k]);
+    const float r2 = r2_f32_exact<D>(d, eps2);
+    int b = -1;
+    if (!tab->degenerate) {
+        b = 0;
+        for (int k = 1; k < tab->levels; ++k) b += (tab->thr[k] <= r2) ? 1 : 0;
+    }
+    bins[(size_t)i * n + j] = (int16_t)b;
+}
+
+template <typename F>
+hipError_t dispatch_dim(int dim, F &&f)
+{
+    if (dim == 2) return f(std::integral_constant<int, 2>{});
+    if (dim == 3) return f(std::integral_constant<int, 3>{});
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+constexpr int R_F32 = 2;
+
+hipError_t nb_launch_force_f64(const double *pos, const double *mass, double *partial, const ForceGeom &g,
+                               int dim, int pa_f32, double G, double eps2_py, hipStream_t st)
+{
+    const int r = pa_f32 ? 2 : g.r;   // the fp32-pair first evaluation is compiled for R = 2 only
+    const dim3 grid((g.n + NB_BLOCK * r - 1) / (NB_BLOCK * r), g.nchunks);
+    const float e32 = (float)eps2_py;
+#define NB_F64(DD, RR, PA) \
+    hipLaunchKernelGGL((force_f64_kernel<DD, RR, PA>), grid, dim3(NB_BLOCK), 0, st, pos, mass, partial, g, G, eps2_py, e32)
+    return dispatch_dim(dim, [&](auto D) {
+        constexpr int DD = decltype(D)::value;
+        if (pa_f32) {
+            NB_F64(DD, 2, true);
+        } else if (g.r == 1) NB_F64(DD, 1, false);
+        else if (g.r == 2) NB_F64(DD, 2, false);
+        else NB_F64(DD, 4, false);
+        return hipGetLastError();
+    });
+#undef NB_F64
+}
+
+hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *partial, const ForceGeom &g,
+                               int dim, int hook, float G, float eps2, const GridTables *tab, hipStream_t st)
+{
+    const dim3 grid((g.n + NB_BLOCK * R_F32 - 1) / (NB_BLOCK * R_F32), g.nchunks);
+    return dispatch_dim(dim, [&](auto D) {
+        constexpr int DD = decltype(D)::value;
+        switch (hook) {
+        case HOOK_NONE:
+            hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HOOK_NONE, 1>), grid, dim3(NB_BLOCK), 0, st, pos,
+                               mass, partial, g, G, eps2, tab);
+            break;
+        case HOOK_BF16:
+            hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HOOK_BF16, 1>), grid, dim3(NB_BLOCK), 0, st, pos,
+                               mass, partial, g, G, eps2, tab);
+            break;
+        case HOOK_F16:
+            hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HOOK_F16, 1>), grid, dim3(NB_BLOCK), 0, st, pos,
+                               mass, partial, g, G, eps2, tab);
+            break;
+        case HOOK_GRID:
+            hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HOOK_GRID, NB_MAX_LUT>), grid, dim3(NB_BLOCK), 0, st,
+                               pos, mass, partial, g, G, eps2, tab);
+            break;
+        default:
+            return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    });
+}
+
+hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float eps2, GridTables *tab,
+                           hipStream_t st)
+{
+    constexpr int R = 4;
+    const dim3 grid((g.n + NB_BLOCK * R - 1) / (NB_BLOCK * R), g.nchunks);
+    return dispatch_dim(dim, [&](auto D) {
+        constexpr int DD = decltype(D)::value;
+        hipLaunchKernelGGL((r2max_kernel<DD, R>), grid, dim3(NB_BLOCK), 0, st, pos, g, eps2, tab);
+        return hipGetLastError();
+    });
+}
+
+hipError_t nb_launch_grid_tables(GridTables *tab, int levels, float G, float eps2, float min_val, hipStream_t st)
+{
+    hipLaunchKernelGGL(grid_tables_kernel, dim3(1), dim3(NB_MAX_LUT), 0, st, tab, levels, G, eps2, min_val);
+    return hipGetLastError();
+}
+
+hipError_t nb_launch_d2bins(const float *pos, int n, int dim, float eps2, const GridTables *tab, int16_t *bins,
+                            hipStream_t st)
+{
+    const dim3 grid((n + NB_BLOCK - 1) / NB_BLOCK, n);
+    return dispatch_dim(dim, [&](auto D) {
+        constexpr int DD = decltype(D)::value;
+        hipLaunchKernelGGL((d2bins_kernel<DD>), grid, dim3(NB_BLOCK), 0, st, pos, n, eps2, tab, bins);
+        return hipGetLastError();
+    });
+}

@@ -1,0 +1,81 @@
+// nb_internal.h -- shared declarations between the C-ABI layer (nb_api.cpp) and the HIP
+// kernels (nb_force.hip, nb_misc.hip).  gfx950 only; no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nbody_amd.h"
+
+// ---- launch geometry ---------------------------------------------------------------------
+constexpr int NB_BLOCK = 256;   // 4 wavefronts of 64
+constexpr int NB_TJ = 256;      // sources staged in LDS per tile (one per thread)
+constexpr int NB_MAX_LUT = 256; // grid levels served by the LDS threshold table
+
+// hooks compiled into the pair loop (quantization.py:21-71)
+enum { HOOK_NONE = 0, HOOK_BF16 = 1, HOOK_F16 = 2, HOOK_GRID = 3 };
+
+// Device-resident grid tables written by grid_tables_kernel, read by the force kernel.
+struct GridTables {
+    float thr[NB_MAX_LUT];   // thr[k] = smallest fp32 r2 whose bin index is >= k (thr[0] = -inf)
+    float lut[NB_MAX_LUT];   // lut[k] = (1 / q_k^1.5) * G   in fp32 (simulation.py:97-101)
+    float qval[NB_MAX_LUT];  // q_k = quantised distance-squared value of bin k
+    float lmin, lmax, range; // log-grid bounds (quantization.py:109-113)
+    float r2max;             // max over all pairs of fp32 r2
+    float fmin, fmax;        // linear force grid bounds (quantization.py:78-79)
+    int degenerate;          // 1: lmax-lmin < 1e-10 -> values pass through clamped
+    int fdegenerate;         // 1: fmax-fmin < 1e-10 -> forces pass through
+    int levels;
+    unsigned int r2max_bits; // atomicMax target (positive floats order as unsigned ints)
+    unsigned int fmin_bits, fmax_bits;
+};
+
+struct ForceGeom {
+    int n;          // particles
+    int j_begin;    // first source of this rank's block
+    int j_end;      // one past the last source of this rank's block
+    int chunk_len;  // sources per blockIdx.y (multiple of NB_TJ)
+    int nchunks;    // gridDim.y
+    int r;          // targets per thread
+};
+
+// ---- kernel launchers (implemented in the .hip files) --------------------------------------
+// T = storage/accumulation type of the state (float or double); pa_f32 != 0 selects fp32
+// pair arithmetic for diff / r2 (always for T=float; for T=double it is the FLOAT64-mode first
+// evaluation on fp32-typed positions).
+hipError_t nb_launch_force_f64(const double *pos, const double *mass, double *partial, const ForceGeom &g,
+                               int dim, int pa_f32, double G, double eps2_py, hipStream_t st);
+hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *partial, const ForceGeom &g,
+                               int dim, int hook, float G, float eps2, const GridTables *tab,
+                               hipStream_t st);
+hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float eps2, GridTables *tab,
+                           hipStream_t st);
+hipError_t nb_launch_grid_tables(GridTables *tab, int levels, float G, float eps2, float min_val,
+                                 hipStream_t st);
+hipError_t nb_launch_d2bins(const float *pos, int n, int dim, float eps2, const GridTables *tab,
+                            int16_t *bins, hipStream_t st);
+
+// reduce the S partial slabs in fixed order; optionally fuse the closing half kick
+hipError_t nb_launch_reduce(const double *partial, int nchunks, int64_t count, void *acc, int is_f64,
+                            void *vel, double half_dt, int do_kick, hipStream_t st);
+hipError_t nb_launch_axpy(void *y, const void *x, double scalar, int64_t count, int is_f64, hipStream_t st);
+hipError_t nb_launch_kick_drift(void *pos, void *vel, const void *acc, double half_dt, double dt,
+                                int64_t count, int is_f64, hipStream_t st);
+hipError_t nb_launch_convert(const void *in, int in_dt, void *out, int out_dt, int64_t count, hipStream_t st);
+
+// linear force grid (quantization.py:74-88) applied in place inside the step, fp32, with bin output
+hipError_t nb_launch_force_quant_bins(const float *in, float *out, int64_t count, int levels, const double *mn_mx,
+                                      int16_t *bins, hipStream_t st);
+
+hipError_t nb_launch_kinetic(const void *vel, const void *mass, int n, int dim, int is_f64, int vel_f32_logical,
+                             double *scratch, double *out, hipStream_t st);
+hipError_t nb_launch_potential(const void *pos, const void *mass, const ForceGeom &g, int dim, int is_f64,
+                               int pa_f32, double eps2_py, double *scratch, double *out, hipStream_t st);
+
+// tensor-level hooks (quantization.py module functions)
+hipError_t nb_launch_cast_hook(const void *in, int in_dt, void *out, int mode, int64_t count, hipStream_t st);
+hipError_t nb_launch_minmax_generic(const void *in, int is_f64, int64_t count, int log_clamped, double min_val,
+                                    double *mn_mx /* device, 2 doubles */, hipStream_t st);
+hipError_t nb_launch_grid_quantize(const void *in, void *out, int is_f64, int64_t count, int levels,
+                                   const double *mn_mx, hipStream_t st);
+hipError_t nb_launch_grid_quantize_safe(const void *in, void *out, int is_f64, int64_t count, int levels,
+                                        double min_val, const double *mn_mx, hipStream_t st);

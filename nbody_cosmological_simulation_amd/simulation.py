@@ -1,0 +1,327 @@
+"""N-body engine front-end -- same Python surface as the reference's simulation.py.
+
+Reference: simulation.py:12-250 (`GalaxySimulation`, `run_comparison`).  Constructor
+arguments, attribute names, method names, defaults, dtype behaviour and error behaviour
+(NaN/Inf propagate silently) are the reference's; everything underneath
+`_compute_accelerations` / `step` / `get_*_energy` is the HIP library behind the C-ABI of
+include/nbody_amd.h.  No tensor arithmetic of the hot path runs in PyTorch: torch tensors
+are only the containers callers read and write.
+
+State ownership.  The authoritative state lives in the library's device buffers.  The
+attributes `positions`, `velocities`, `masses`, `accelerations` are torch tensors
+materialised on demand (on `self.device`, with the dtype the reference would show at that
+moment) and cached until the next step.  A caller that edits such a tensor in place
+(omega_point_test.py:738) or rebinds the attribute is detected through the tensor's version
+counter / identity and the array is re-uploaded before the next native call.
+
+Subclass rule: `__init__` and `step` dispatch through
+`self._compute_accelerations()`; when a subclass overrides it (sensitivity_test.py:55-76 and
+17 clones) its returned tensor becomes the force and only the two kicks and the drift run
+natively; otherwise the whole step is one native call.
+"""
+import ctypes as C
+from typing import Callable
+
+import torch
+
+from . import _native as N
+from . import runtime
+from .quantization import PrecisionMode, mode_code, _TORCH_TO_NB, _NB_TO_TORCH
+
+_ARRAYS = ("positions", "velocities", "masses", "accelerations")
+_IDX = {"positions": 0, "velocities": 1, "masses": 2, "accelerations": 3}
+
+
+class GalaxySimulation:
+    """N-body gravitational simulation with configurable precision (reference simulation.py:12)."""
+
+    def __init__(
+        self,
+        positions: torch.Tensor,
+        velocities: torch.Tensor,
+        masses: torch.Tensor,
+        precision_mode: PrecisionMode = PrecisionMode.FLOAT64,
+        G: float = 0.001,
+        softening: float = 0.1,
+        dt: float = 0.01,
+        device: torch.device = None,
+        custom_levels: int = None,
+        profile: bool = False,
+        shard: tuple = None,
+    ):
+        # reference simulation.py:54-66
+        self.device = torch.device(device) if device is not None else positions.device
+        self.precision_mode = precision_mode
+        self.G = G
+        self.softening = softening
+        self.softening_sq = softening ** 2
+        self.dt = dt
+        self.num_stars = len(masses)
+        self.custom_levels = custom_levels
+
+        if positions.dim() != 2 or positions.shape[1] not in (2, 3):
+            raise ValueError(f"positions must be (N, 2) or (N, 3), got {tuple(positions.shape)}")
+        if positions.shape[0] != self.num_stars or velocities.shape != positions.shape:
+            raise ValueError("positions, velocities and masses disagree on N")
+
+        self._handle = C.c_void_p()
+        self._cfg_dim = int(positions.shape[1])
+        self._cache = {}        # name -> [tensor, version, dirty]
+        self._native_acc = None
+        rank, world = runtime.rank_world()
+        flags = N.NB_FLAG_PROFILE if profile else 0
+        if shard is not None:
+            # explicit (rank, world) without a communicator: this handle only produces the partial
+            # sums of its source block (single-GPU shard tests / caller-side reduction)
+            rank, world = int(shard[0]), int(shard[1])
+            flags |= N.NB_FLAG_NO_COMM
+        if self.device.type == "cuda":
+            dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        else:
+            dev = runtime.default_hip_device()
+        cfg = N.NbConfig(
+            n=self.num_stars, dim=int(positions.shape[1]), mode=mode_code(precision_mode),
+            levels=int(custom_levels or 0), G=float(G), softening_sq=float(self.softening_sq), dt=float(dt),
+            device=int(dev), rank=rank, nranks=world,
+            flags=flags)
+        N.check(N.lib().nb_create(C.byref(self._handle), C.byref(cfg)))
+        if world > 1 and shard is None:
+            uid = runtime.exchange_unique_id()
+            N.check(N.lib().nb_comm_init(self._handle, uid, len(uid)))
+
+        # simulation.py:63-65: clone -> device.  The clone is the upload itself.
+        self._upload("positions", positions)
+        self._upload("velocities", velocities)
+        self._upload("masses", masses)
+
+        # simulation.py:69 (virtual call: subclasses may override _compute_accelerations)
+        self.accelerations = self._compute_accelerations()
+        self.tick = 0
+
+    # ------------------------------------------------------------------ native plumbing
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                N.lib().nb_destroy(h)
+            except Exception:
+                pass
+            h.value = None
+
+    def _upload(self, name, tensor):
+        t = tensor.detach()
+        if t.dtype not in _TORCH_TO_NB:
+            raise TypeError(f"{name}: unsupported dtype {t.dtype}")
+        t = t.contiguous()
+        on_device = t.device.type == "cuda"
+        if on_device:
+            torch.cuda.current_stream(t.device).synchronize()
+        ptr = C.c_void_p(t.data_ptr())
+        code = _TORCH_TO_NB[t.dtype]
+        L = N.lib()
+        if name == "accelerations":
+            N.check(L.nb_set_accelerations(self._handle, ptr, code, int(on_device)))
+        else:
+            args = {"positions": (ptr, None, None), "velocities": (None, ptr, None), "masses": (None, None, ptr)}[name]
+            N.check(L.nb_set_state(self._handle, args[0], args[1], args[2], code, int(on_device)))
+
+    def _download(self, name):
+        dts = (C.c_int32 * 4)()
+        N.check(N.lib().nb_state_dtypes(self._handle, dts))
+        dtype = _NB_TO_TORCH[dts[_IDX[name]]]
+        shape = (self.num_stars,) if name == "masses" else (self.num_stars, self._dim())
+        out = torch.empty(shape, dtype=dtype, device=self.device)
+        on_device = out.device.type == "cuda"
+        ptr = C.c_void_p(out.data_ptr())
+        args = [None, None, None, None]
+        args[{"positions": 0, "velocities": 1, "accelerations": 2, "masses": 3}[name]] = ptr
+        N.check(N.lib().nb_get_state(self._handle, args[0], args[1], args[2], args[3], int(on_device)))
+        return out
+
+    def _dim(self):
+        return self._cfg_dim
+
+    def _get(self, name):
+        ent = self._cache.get(name)
+        if ent is None:
+            t = self._download(name)
+            self._cache[name] = [t, t._version, False]
+            return t
+        return ent[0]
+
+    def _set(self, name, value):
+        if not isinstance(value, torch.Tensor):
+            raise TypeError(f"{name} must be a torch.Tensor")
+        if name == "accelerations" and value is self._native_acc:
+            self._cache[name] = [value, value._version, False]     # produced by the library itself
+        else:
+            self._cache[name] = [value, value._version, True]
+
+    positions = property(lambda s: s._get("positions"), lambda s, v: s._set("positions", v))
+    velocities = property(lambda s: s._get("velocities"), lambda s, v: s._set("velocities", v))
+    masses = property(lambda s: s._get("masses"), lambda s, v: s._set("masses", v))
+    accelerations = property(lambda s: s._get("accelerations"), lambda s, v: s._set("accelerations", v))
+
+    def _flush(self, names=_ARRAYS):
+        """Push caller-side edits (in-place writes or rebinding) down to the device state."""
+        for name in names:
+            ent = self._cache.get(name)
+            if ent is None:
+                continue
+            t, ver, dirty = ent
+            if dirty or t._version != ver:
+                self._upload(name, t)
+                ent[1], ent[2] = t._version, False
+        # attribute writes such as `sim.dt = 0.02` (simulation.py reads them at every use)
+        N.check(N.lib().nb_set_params(self._handle, float(self.G), float(self.softening_sq), float(self.dt)))
+
+    def _invalidate(self, *names):
+        for name in names:
+            self._cache.pop(name, None)
+
+    def _overridden(self):
+        return type(self)._compute_accelerations is not GalaxySimulation._compute_accelerations
+
+    # ------------------------------------------------------------------ hot path
+    def _compute_accelerations(self) -> torch.Tensor:
+        """All-pairs softened gravity with the precision hook of `self.precision_mode`
+        (reference simulation.py:74-118) -- one native call, result returned as a tensor."""
+        self._flush(("positions", "masses"))
+        N.check(N.lib().nb_compute_accelerations(self._handle))
+        self._invalidate("accelerations")
+        acc = self._download("accelerations")
+        self._native_acc = acc
+        return acc
+
+    compute_forces = _compute_accelerations   # north-star alias
+
+    def step(self):
+        """One kick-drift-kick leapfrog step (reference simulation.py:120-143)."""
+        L = N.lib()
+        if self._overridden():
+            self._flush()
+            N.check(L.nb_kick_drift(self._handle))                   # :132, :135
+            self._invalidate("positions", "velocities")
+            self.accelerations = self._compute_accelerations()        # :138 (subclass code)
+            self._flush(("accelerations",))
+            N.check(L.nb_kick(self._handle))                         # :141
+            self._invalidate("velocities")
+        else:
+            self._flush()
+            N.check(L.nb_step(self._handle, 1))
+            self._invalidate("positions", "velocities", "accelerations")
+        self.tick += 1
+
+    def run(self, num_ticks: int, callback: Callable = None, callback_interval: int = 100):
+        """Run `num_ticks` steps; `callback(self, self.tick)` every `callback_interval`
+        (reference simulation.py:145-158)."""
+        fused = (not self._overridden()) and type(self).step is GalaxySimulation.step
+        if not fused:
+            for t in range(num_ticks):
+                self.step()
+                if callback and (t + 1) % callback_interval == 0:
+                    callback(self, self.tick)
+            return
+        # whole stretches between callbacks stay on the device: one native call each
+        done = 0
+        while done < num_ticks:
+            if callback:
+                nxt = min(num_ticks, (done // callback_interval + 1) * callback_interval)
+            else:
+                nxt = num_ticks
+            self._flush()
+            N.check(N.lib().nb_step(self._handle, nxt - done))
+            self._invalidate("positions", "velocities", "accelerations")
+            self.tick += nxt - done
+            done = nxt
+            if callback and done % callback_interval == 0:
+                callback(self, self.tick)
+
+    def get_state(self) -> dict:
+        """Current state as clones (reference simulation.py:160-168)."""
+        return {
+            "positions": self.positions.clone(),
+            "velocities": self.velocities.clone(),
+            "masses": self.masses.clone(),
+            "tick": self.tick,
+            "precision_mode": self.precision_mode.value,
+        }
+
+    def get_kinetic_energy(self) -> float:
+        """sum(0.5 * m * v^2) (reference simulation.py:170-174)."""
+        self._flush(("velocities", "masses"))
+        ke = C.c_double()
+        N.check(N.lib().nb_energy(self._handle, C.byref(ke), None))
+        return ke.value
+
+    def get_potential_energy(self) -> float:
+        """-G * sum_{i<j} m_i m_j / sqrt(r_ij^2 + eps^2) (reference simulation.py:176-192)."""
+        self._flush(("positions", "masses"))
+        pe = C.c_double()
+        N.check(N.lib().nb_energy(self._handle, None, C.byref(pe)))
+        return pe.value
+
+    def get_total_energy(self) -> float:
+        """Total mechanical energy (reference simulation.py:194-196)."""
+        return self.get_kinetic_energy() + self.get_potential_energy()
+
+    # ------------------------------------------------------------------ extras (not in the reference)
+    def synchronize(self):
+        N.check(N.lib().nb_synchronize(self._handle))
+
+    def kernel_time(self):
+        """(total_ms, launches) of the force kernel since the last call (needs profile=True)."""
+        ms, n = C.c_double(), C.c_int32()
+        N.check(N.lib().nb_kernel_time(self._handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def quant_debug(self, bins: bool = False):
+        """Grid internals of the last force evaluation (INT8/INT4/CUSTOM modes)."""
+        import numpy as np
+        info = (C.c_double * 5)()
+        n, d = self.num_stars, self._dim()
+        d2 = np.empty((n, n), np.int16) if bins else None
+        has_fq = self.precision_mode in (PrecisionMode.INT8_SIM, PrecisionMode.INT4_SIM)
+        fb = np.empty((n, d), np.int16) if (bins and has_fq) else None
+        N.check(N.lib().nb_quant_debug(self._handle, info,
+                                       None if d2 is None else d2.ctypes.data_as(C.c_void_p),
+                                       None if fb is None else fb.ctypes.data_as(C.c_void_p)))
+        return dict(lmin=info[0], lmax=info[1], fmin=info[2], fmax=info[3], r2max=info[4], d2bins=d2, fbins=fb)
+
+
+def run_comparison(
+    positions: torch.Tensor,
+    velocities: torch.Tensor,
+    masses: torch.Tensor,
+    modes: list,
+    num_ticks: int = 1000,
+    callback: Callable = None,
+    callback_interval: int = 100,
+    **sim_kwargs
+) -> dict:
+    """Same initial conditions under several precision modes (reference simulation.py:199-250)."""
+    results = {}
+    for mode in modes:
+        print(f"\nRunning simulation with {mode.value} precision...")
+        sim = GalaxySimulation(positions.clone(), velocities.clone(), masses.clone(),
+                               precision_mode=mode, **sim_kwargs)
+        history = {
+            "positions": [positions.clone().cpu()],
+            "energies": [sim.get_total_energy()],
+            "ticks": [0],
+        }
+
+        def record_callback(s, tick, history=history):
+            history["positions"].append(s.positions.clone().cpu())
+            history["energies"].append(s.get_total_energy())
+            history["ticks"].append(tick)
+            if callback:
+                callback(s, tick)
+
+        sim.run(num_ticks, callback=record_callback, callback_interval=callback_interval)
+        results[mode.value] = {
+            "final_state": sim.get_state(),
+            "history": history,
+            "simulation": sim,
+        }
+    return results

@@ -1,0 +1,90 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/nbody_amd.h declares, and refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "nbody_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nbody_cosmological_simulation_amd import _native
+    lib = _native.lib()
+    declared = header_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/nbody_amd.h but not exported"
+    assert sorted(_native.EXPORTS) == declared
+    assert lib.nb_abi_version() == 1
+
+
+def test_config_struct_layout_matches_header():
+    from nbody_cosmological_simulation_amd import _native
+    # 4 int32, 3 double, 4 int32 -> 16 + 24 + 16 bytes, no padding surprises
+    assert C.sizeof(_native.NbConfig) == 56
+    assert _native.NbConfig.G.offset == 16 and _native.NbConfig.device.offset == 40
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_gpu_means_loud_failure_not_fallback():
+    import nbody_cosmological_simulation_amd as nb
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nb.GalaxySimulation(torch.randn(8, 2), torch.randn(8, 2), torch.ones(8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nb._grid_quantize_safe(torch.rand(4, 4), 16)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "nbody_cosmological_simulation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.lower(), f"{f} mentions the oracle"
+
+
+def test_mode_helpers_match_reference_tables():
+    import json
+    import nbody_cosmological_simulation_amd as nb
+    api = json.load(open(os.path.join(ROOT, "tests", "golden", "api.json")))
+    for s, v in api["mode_from_string"].items():
+        assert nb.get_mode_from_string(s).value == v
+    for m, text in api["describe_mode"].items():
+        assert nb.describe_mode(nb.PrecisionMode(m)) == text
+    assert {m.name: m.value for m in nb.PrecisionMode} == api["precision_mode_members"]
+
+
+def test_shard_ranges_tile_the_sources():
+    from nbody_cosmological_simulation_amd.runtime import shard_range
+    for n in (1, 7, 257, 65536, 1048576):
+        for world in (1, 2, 3, 8):
+            edges = [shard_range(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+
+
+def test_galaxy_generators_reproduce_reference_draws():
+    import numpy as np
+    from conftest import load_golden
+    from nbody_cosmological_simulation_amd import galaxy
+    g = load_golden("g6_galaxy_metrics.npz")
+    for name, fn, kw in (("disk", galaxy.create_disk_galaxy, dict(num_stars=2000)),
+                         ("test", galaxy.create_test_galaxy, dict(num_stars=1000)),
+                         ("halo", galaxy.create_galaxy_with_halo, dict(num_stars=1500))):
+        torch.manual_seed(7)
+        p, v, m = fn(device="cpu", **kw)
+        assert p.dtype == torch.float32
+        assert np.allclose(p.numpy(), g[f"{name}/pos"], rtol=0, atol=1e-6)
+        assert np.allclose(v.numpy(), g[f"{name}/vel"], rtol=0, atol=1e-6)
+        assert np.array_equal(m.numpy(), g[f"{name}/mass"])
+    r = torch.from_numpy(g["nfw_r"])
+    assert np.allclose(galaxy.nfw_enclosed_mass(r, 5000.0, 30.0).numpy(), g["nfw"], rtol=1e-6)
