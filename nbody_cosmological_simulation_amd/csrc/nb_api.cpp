@@ -521,7 +521,7 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential)
     if (potential) {
         if (!s->have_pos || !s->have_mass) return fail(NB_ERR_INVALID, "positions/masses not set");
         HIPCHK(nb_launch_potential(s->pos, s->mass, s->geom, c.dim, s->is_f64, s->logical[0] != NB_F64,
-                                   c.softening_sq, s->scratch, s->scalars + 3, s->stream));
+                                   s->logical[2] != NB_F64, c.softening_sq, s->scratch, s->scalars + 3, s->stream));
         if (c.nranks > 1 && !(c.flags & NB_FLAG_NO_COMM)) {
             if (!s->comm) return fail(NB_ERR_COMM, "nranks > 1 but nb_comm_init was not called");
             NCCLCHK(g_rccl.AllReduce(s->scalars + 3, s->scalars + 3, 1, ncclDouble, ncclSum, s->comm, s->stream));

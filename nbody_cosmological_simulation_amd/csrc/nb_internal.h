@@ -69,7 +69,8 @@ hipError_t nb_launch_force_quant_bins(const float *in, float *out, int64_t count
 hipError_t nb_launch_kinetic(const void *vel, const void *mass, int n, int dim, int is_f64, int vel_f32_logical,
                              double *scratch, double *out, hipStream_t st);
 hipError_t nb_launch_potential(const void *pos, const void *mass, const ForceGeom &g, int dim, int is_f64,
-                               int pa_f32, double eps2_py, double *scratch, double *out, hipStream_t st);
+                               int pa_f32, int mass_f32, double eps2_py, double *scratch, double *out,
+                               hipStream_t st);
 
 // tensor-level hooks (quantization.py module functions)
 hipError_t nb_launch_cast_hook(const void *in, int in_dt, void *out, int mode, int64_t count, hipStream_t st);

@@ -279,7 +279,7 @@ final_sum_kernel(const double *__restrict__ part, int count, double *__restrict_
 template <typename T, int D, bool PA_F32>
 __global__ void __launch_bounds__(NB_BLOCK)
 potential_kernel(const T *__restrict__ pos, const T *__restrict__ mass, ForceGeom g, double eps2, float eps2_f,
-                 double *__restrict__ part)
+                 int mass_f32, double *__restrict__ part)
 {
     __shared__ T sj[D + 1][NB_TJ];
     __shared__ double s_red[NB_BLOCK / 64];
@@ -331,7 +331,11 @@ potential_kernel(const T *__restrict__ pos, const T *__restrict__ mass, ForceGeo
                 const double y0 = __builtin_amdgcn_rsq(q);
                 const double e = __builtin_fma(-q * y0, y0, 1.0);
                 const double y = __builtin_fma(y0 * e, __builtin_fma(e, 0.375, 0.5), y0);
-                term = ((double)mi * (double)sj[D][jj]) * y;
+                // mass_prod keeps the masses' dtype upstream (simulation.py:185): fp32-typed masses
+                // give an fp32-rounded product even when positions are already fp64
+                const double mp = mass_f32 ? (double)__fmul_rn((float)mi, (float)sj[D][jj])
+                                           : (double)mi * (double)sj[D][jj];
+                term = mp * y;
             }
             s += take ? term : 0.0;
         }
@@ -494,12 +498,13 @@ hipError_t nb_launch_kinetic(const void *vel, const void *mass, int n, int dim, 
 }
 
 hipError_t nb_launch_potential(const void *pos, const void *mass, const ForceGeom &g, int dim, int is_f64,
-                               int pa_f32, double eps2_py, double *scratch, double *out, hipStream_t st)
+                               int pa_f32, int mass_f32, double eps2_py, double *scratch, double *out,
+                               hipStream_t st)
 {
     const dim3 grid((g.n + NB_BLOCK - 1) / NB_BLOCK, g.nchunks);
     const float e32 = (float)eps2_py;
 #define NB_PE(T, D, PA) \
-    hipLaunchKernelGGL((potential_kernel<T, D, PA>), grid, dim3(NB_BLOCK), 0, st, (const T *)pos, (const T *)mass, g, eps2_py, e32, scratch)
+    hipLaunchKernelGGL((potential_kernel<T, D, PA>), grid, dim3(NB_BLOCK), 0, st, (const T *)pos, (const T *)mass, g, eps2_py, e32, mass_f32, scratch)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64) {
         if (pa_f32) { if (dim == 2) NB_PE(double, 2, true); else NB_PE(double, 3, true); }
