@@ -70,6 +70,20 @@ def cpu_baseline(pos, vel, mass, target_s):
     }
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary (collected
+    in separate --pmc passes as the MI355X guide prescribes), or None when not profiled yet."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        summary = json.load(open(path))
+    except OSError:
+        return None
+    for name, counters in summary.items():
+        if name.startswith(kernel_name) and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+            return (2.0 * counters["FETCH_SIZE"]["avg"] + counters["WRITE_SIZE"]["avg"]) * 1024.0
+    return None
+
+
 def main():
     args = parse()
     import torch
@@ -81,7 +95,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ          # under torch.distributed.run, also with one rank
+    if launched:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -98,7 +113,7 @@ def main():
                               G=0.001, softening=0.1, dt=0.01, device=dev, profile=True)
 
     def barrier():
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize()
         sim.synchronize()
@@ -117,6 +132,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms, launches = sim.kernel_time()
+    kernel_name = sim.force_kernel_name()
     e1 = sim.get_total_energy()
 
     if rank == 0:
@@ -143,17 +159,20 @@ def main():
             "energy_drift_rel": (e1 - e0) / abs(e0),
             "roofline": {
                 "bound": "valu", "bound_note": "fp64 vector ALU (compute-bound; HBM traffic is O(N) per step)",
-                "kernel": "force_f64_kernel" if is64 else "force_f32_kernel",
+                "kernel": kernel_name,
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "avg_launch_ms": avg_ms, "launches": launches,
                 "flop_per_launch": FLOP_PER_PAIR_2D * pairs_per_launch,
-                "traffic": None,
+                "traffic": pmc_traffic(kernel_name),
+                "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes committed under profiles/ "
+                                "(2*FETCH_SIZE + WRITE_SIZE, gfx950 correction); dominated by the slab writes "
+                                "that make the sums order-deterministic, DESIGN.md section 2",
             },
         }
         if world == 1 and not args.no_cpu_baseline and is64:
             out["cpu_baseline"] = cpu_baseline(pos, vel, mass, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

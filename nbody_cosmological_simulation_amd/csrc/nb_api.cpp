@@ -106,6 +106,14 @@ struct nb_sim {
     double *scalars = nullptr;           // device: [0,1] force min/max, [2] ke, [3] pe
     int16_t *fbins = nullptr;            // n*dim, INT8/INT4 only
     ForceGeom geom{};
+    // pair-symmetric fp64 path (nb_force_sym.hip)
+    struct SymPlan {
+        bool enabled = false;
+        int r = 2, tile_b = 128, tiles = 0, np = 0, nwork = 0, nslots = 0, nrows = 0;
+        SymWork *work = nullptr;
+        int *row_slot0 = nullptr, *row_nslots = nullptr, *row_ord = nullptr;
+        double *packed = nullptr, *rowslab = nullptr, *colslab = nullptr;
+    } sym;
     ncclComm_t comm = nullptr;
     // profiling
     hipEvent_t ev_start[PROF_RING], ev_stop[PROF_RING];
@@ -156,6 +164,73 @@ void compute_geometry(nb_sim *s)
     s->geom = g;
 }
 
+// Work list of the pair-symmetric kernel.  Rows (target tiles) are dealt to the ranks in a snake
+// pattern so every rank owns the same number of tile pairs to within one row; each owned row is
+// cut into chunks of `cl` source tiles = one workgroup each, longest chunks first.
+int build_sym_plan(nb_sim *s)
+{
+    auto &sp = s->sym;
+    sp.enabled = false;
+    const nb_config &c = s->cfg;
+    int want = (c.n >= 4096) ? 1 : 0;
+    if (const char *e = getenv("NB_SYM")) want = atoi(e);
+    if (!want || (c.flags & NB_FLAG_NO_COMM)) return NB_OK;
+    sp.r = (c.dim == 2) ? 4 : 2;       // measured on MI355X, N=65536: R=1 3.39 ms, R=2 1.87 ms, R=4 1.47 ms
+    if (const char *e = getenv("NB_SYM_R")) {
+        const int r = atoi(e);
+        if (r == 1 || r == 2 || (r == 4 && c.dim == 2)) sp.r = r;
+    }
+    sp.tile_b = 64 * sp.r;
+    sp.tiles = (c.n + sp.tile_b - 1) / sp.tile_b;
+    sp.np = sp.tiles * sp.tile_b;
+    const int T = sp.tiles, P = c.nranks;
+    std::vector<int> owner(T), ord(T, -1), slot0(T, 0), nslots(T, 0);
+    long long owned_pairs = 0;
+    int nrows = 0;
+    for (int I = 0; I < T; ++I) {
+        const int k = I % (2 * P);
+        owner[I] = k < P ? k : 2 * P - 1 - k;
+        if (owner[I] == c.rank) { ord[I] = nrows++; owned_pairs += T - I; }
+    }
+    int cl = (int)((owned_pairs / 2048 + 3) / 4 * 4);
+    cl = std::max(4, std::min(cl, 64));
+    if (const char *e = getenv("NB_SYM_CL")) cl = std::max(4, atoi(e) / 4 * 4);
+    std::vector<SymWork> work;
+    int slots = 0;
+    for (int I = 0; I < T; ++I) {
+        if (ord[I] < 0) continue;
+        slot0[I] = slots;
+        for (int jb = I; jb < T; jb += cl) {
+            SymWork w{I, jb, std::min(T, jb + cl), slots++, ord[I]};
+            work.push_back(w);
+        }
+        nslots[I] = slots - slot0[I];
+    }
+    std::stable_sort(work.begin(), work.end(), [](const SymWork &a, const SymWork &b) {
+        return (a.jt_end - a.jt_begin) > (b.jt_end - b.jt_begin);
+    });
+    const size_t slab = (size_t)c.dim * sp.np * sizeof(double);
+    const size_t col_bytes = slab * (size_t)std::max(nrows, 1);
+    if (col_bytes > (size_t)48 << 30) return NB_OK;       // fall back to the one-sided kernel
+    sp.nwork = (int)work.size();
+    sp.nslots = slots;
+    sp.nrows = nrows;
+    if (sp.nwork == 0) return NB_OK;
+    HIPCHK(hipMalloc((void **)&sp.work, work.size() * sizeof(SymWork)));
+    HIPCHK(hipMalloc((void **)&sp.row_slot0, T * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&sp.row_nslots, T * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&sp.row_ord, T * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&sp.packed, (size_t)(c.dim + 1) * sp.np * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&sp.rowslab, slab * (size_t)std::max(slots, 1)));
+    HIPCHK(hipMalloc((void **)&sp.colslab, col_bytes));
+    HIPCHK(hipMemcpy(sp.work, work.data(), work.size() * sizeof(SymWork), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp.row_slot0, slot0.data(), T * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp.row_nslots, nslots.data(), T * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp.row_ord, ord.data(), T * sizeof(int), hipMemcpyHostToDevice));
+    sp.enabled = true;
+    return NB_OK;
+}
+
 int ensure_storage(nb_sim *s, bool f64)
 {
     if (s->have_storage) {
@@ -183,6 +258,7 @@ int ensure_storage(nb_sim *s, bool f64)
     HIPCHK(hipMemsetAsync(s->scalars, 0, 8 * sizeof(double), s->stream));
     if (force_quant_mode(s->cfg)) HIPCHK(hipMalloc((void **)&s->fbins, cnt * sizeof(int16_t)));
     HIPCHK(hipMemsetAsync(s->acc, 0, cnt * el, s->stream));
+    if (f64) if (int rc = build_sym_plan(s)) return rc;
     s->have_storage = true;
     return NB_OK;
 }
@@ -276,19 +352,33 @@ int force_eval(nb_sim *s, bool do_kick)
     const double half_dt = c.dt / 2;
     const bool fq = force_quant_mode(c) && !((c.flags & NB_FLAG_NO_COMM) && c.nranks > 1);
     const bool no_comm = (c.flags & NB_FLAG_NO_COMM) != 0;
-    const bool multi = c.nranks > 1 && !no_comm;
+    // collectives run whenever a communicator exists (a 1-rank communicator exercises the same
+    // RCCL calls on a single GPU) and must exist when the sources are really sharded
+    const bool multi = (c.nranks > 1 && !no_comm) || s->comm != nullptr;
     if (multi && !s->comm) return fail(NB_ERR_COMM, "nranks > 1 but nb_comm_init was not called");
     if (no_comm && c.nranks > 1 && do_kick) return fail(NB_ERR_INVALID, "NB_FLAG_NO_COMM handles cannot step");
     int slot;
+    bool used_sym = false;
 
     if (s->is_f64) {
         if (c.mode != NB_FLOAT64)
             return fail(NB_ERR_UNSUPPORTED, "fp64 state with a non-FLOAT64 precision mode is not implemented yet");
         const int pa_f32 = (s->logical[0] == NB_F32);
-        if (int rc = prof_begin(s, &slot)) return rc;
-        HIPCHK(nb_launch_force_f64((const double *)s->pos, (const double *)s->mass, s->partial, s->geom, c.dim,
-                                   pa_f32, c.G, c.softening_sq, s->stream));
-        if (int rc = prof_end(s, slot)) return rc;
+        used_sym = s->sym.enabled && !pa_f32;
+        if (used_sym) {
+            const auto &sp = s->sym;
+            HIPCHK(nb_launch_pack_f64((const double *)s->pos, (const double *)s->mass, sp.packed, c.n, sp.np, c.dim,
+                                      c.G, s->stream));
+            if (int rc = prof_begin(s, &slot)) return rc;
+            HIPCHK(nb_launch_force_sym_f64(sp.packed, sp.work, sp.nwork, sp.rowslab, sp.colslab, sp.np, c.dim, sp.r,
+                                           c.softening_sq, s->stream));
+            if (int rc = prof_end(s, slot)) return rc;
+        } else {
+            if (int rc = prof_begin(s, &slot)) return rc;
+            HIPCHK(nb_launch_force_f64((const double *)s->pos, (const double *)s->mass, s->partial, s->geom, c.dim,
+                                       pa_f32, c.G, c.softening_sq, s->stream));
+            if (int rc = prof_end(s, slot)) return rc;
+        }
     } else {
         int hook = HOOK_NONE;
         if (c.mode == NB_BFLOAT16) hook = HOOK_BF16;
@@ -320,8 +410,15 @@ int force_eval(nb_sim *s, bool do_kick)
     }
 
     const bool fuse_kick = do_kick && !multi && !fq;
-    HIPCHK(nb_launch_reduce(s->partial, s->geom.nchunks, cnt, s->acc, s->is_f64, s->vel, half_dt, fuse_kick,
-                            s->stream));
+    if (used_sym) {
+        const auto &sp = s->sym;
+        HIPCHK(nb_launch_reduce_sym_f64(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.row_ord, sp.tile_b,
+                                        c.n, sp.np, c.dim, (double *)s->acc, (double *)s->vel, half_dt, fuse_kick,
+                                        s->stream));
+    } else {
+        HIPCHK(nb_launch_reduce(s->partial, s->geom.nchunks, cnt, s->acc, s->is_f64, s->vel, half_dt, fuse_kick,
+                                s->stream));
+    }
     if (multi)
         NCCLCHK(g_rccl.AllReduce(s->acc, s->acc, (size_t)cnt, s->is_f64 ? ncclDouble : ncclFloat, ncclSum, s->comm,
                                  s->stream));
@@ -395,7 +492,9 @@ int nb_destroy(nb_sim *s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (void *p : {s->pos, s->vel, s->mass, s->acc, (void *)s->partial, s->staging, (void *)s->tab,
-                    (void *)s->scratch, (void *)s->scalars, (void *)s->fbins})
+                    (void *)s->scratch, (void *)s->scalars, (void *)s->fbins, (void *)s->sym.work,
+                    (void *)s->sym.row_slot0, (void *)s->sym.row_nslots, (void *)s->sym.row_ord,
+                    (void *)s->sym.packed, (void *)s->sym.rowslab, (void *)s->sym.colslab})
         if (p) (void)hipFree(p);
     if (s->prof_init)
         for (int i = 0; i < PROF_RING; ++i) { (void)hipEventDestroy(s->ev_start[i]); (void)hipEventDestroy(s->ev_stop[i]); }
@@ -522,7 +621,7 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential)
         if (!s->have_pos || !s->have_mass) return fail(NB_ERR_INVALID, "positions/masses not set");
         HIPCHK(nb_launch_potential(s->pos, s->mass, s->geom, c.dim, s->is_f64, s->logical[0] != NB_F64,
                                    s->logical[2] != NB_F64, c.softening_sq, s->scratch, s->scalars + 3, s->stream));
-        if (c.nranks > 1 && !(c.flags & NB_FLAG_NO_COMM)) {
+        if ((c.nranks > 1 && !(c.flags & NB_FLAG_NO_COMM)) || s->comm) {
             if (!s->comm) return fail(NB_ERR_COMM, "nranks > 1 but nb_comm_init was not called");
             NCCLCHK(g_rccl.AllReduce(s->scalars + 3, s->scalars + 3, 1, ncclDouble, ncclSum, s->comm, s->stream));
         }

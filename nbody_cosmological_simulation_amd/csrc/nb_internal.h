@@ -38,6 +38,23 @@ struct ForceGeom {
     int r;          // targets per thread
 };
 
+// One workgroup of the pair-symmetric kernel: target tile `tile_i` against source tiles
+// [jt_begin, jt_end) (jt_begin >= tile_i; the four waves take them round-robin).
+struct SymWork {
+    int tile_i;
+    int jt_begin, jt_end;
+    int slot;      // row-slab slot this workgroup writes its target-tile sums to
+    int row_ord;   // ordinal of row tile_i among the rows this rank owns (column-slab index)
+};
+
+hipError_t nb_launch_pack_f64(const double *pos, const double *mass, double *packed, int n, int np, int dim,
+                              double G, hipStream_t st);
+hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, int nwork, double *rowslab,
+                                   double *colslab, int np, int dim, int r, double eps2, hipStream_t st);
+hipError_t nb_launch_reduce_sym_f64(const double *rowslab, const double *colslab, const int *row_slot0,
+                                    const int *row_nslots, const int *row_ord, int tile_b, int n, int np, int dim,
+                                    double *acc, double *vel, double half_dt, int do_kick, hipStream_t st);
+
 // ---- kernel launchers (implemented in the .hip files) --------------------------------------
 // T = storage/accumulation type of the state (float or double); pa_f32 != 0 selects fp32
 // pair arithmetic for diff / r2 (always for T=float; for T=double it is the FLOAT64-mode first

@@ -54,14 +54,29 @@ def rank_world():
     return _ctx["rank"], _ctx["world"]
 
 
-def exchange_unique_id() -> bytes:
+def force_comm() -> bool:
+    """NBODY_FORCE_COMM=1: create the RCCL communicator even for one rank, so a single-GPU box
+    exercises nb_comm_init and the all-reduce calls of the multi-GPU step."""
+    return os.environ.get("NBODY_FORCE_COMM", "0") == "1" and _ctx["world"] >= 1 and _dist_ready()
+
+
+def _dist_ready() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+def _draw_unique_id() -> bytes:
+    buf = C.create_string_buffer(256)
+    size = C.c_int32(256)
+    N.check(N.lib().nb_comm_unique_id(buf, C.byref(size)))
+    return bytes(buf.raw[: size.value])
+
+
+def exchange_unique_id(draw=_draw_unique_id) -> bytes:
     """Rank 0 draws an RCCL unique id (nb_comm_unique_id); everyone receives its bytes."""
     import torch.distributed as dist
     payload = [None]
     if _ctx["rank"] == 0:
-        buf = C.create_string_buffer(256)
-        size = C.c_int32(256)
-        N.check(N.lib().nb_comm_unique_id(buf, C.byref(size)))
-        payload[0] = bytes(buf.raw[: size.value])
+        payload[0] = draw()
     dist.broadcast_object_list(payload, src=0, group=_ctx["group"])
     return payload[0]

@@ -85,7 +85,7 @@ class GalaxySimulation:
             device=int(dev), rank=rank, nranks=world,
             flags=flags)
         N.check(N.lib().nb_create(C.byref(self._handle), C.byref(cfg)))
-        if world > 1 and shard is None:
+        if shard is None and (world > 1 or runtime.force_comm()):
             uid = runtime.exchange_unique_id()
             N.check(N.lib().nb_comm_init(self._handle, uid, len(uid)))
 
@@ -274,6 +274,18 @@ class GalaxySimulation:
         ms, n = C.c_double(), C.c_int32()
         N.check(N.lib().nb_kernel_time(self._handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def force_kernel_name(self) -> str:
+        """Name of the kernel nb_step uses for the force sum in the current state (for profiles)."""
+        import os
+        dts = (C.c_int32 * 4)()
+        N.check(N.lib().nb_state_dtypes(self._handle, dts))
+        if self.precision_mode != PrecisionMode.FLOAT64:
+            return "force_f32_kernel"
+        sym_default = "1" if self.num_stars >= 4096 else "0"
+        if os.environ.get("NB_SYM", sym_default) == "1" and dts[0] == N.NB_F64:
+            return "force_sym_f64_kernel"
+        return "force_f64_kernel"
 
     def quant_debug(self, bins: bool = False):
         """Grid internals of the last force evaluation (INT8/INT4/CUSTOM modes)."""

@@ -386,3 +386,62 @@ def test_errors_are_exceptions(nb):
         nb.GalaxySimulation(torch.zeros(4, 4), torch.zeros(4, 4), torch.ones(4))
     with pytest.raises(Exception):
         nb.GalaxySimulation(torch.zeros(4, 2).half(), torch.zeros(4, 2).half(), torch.ones(4).half())
+
+
+def test_rccl_path_with_one_rank_communicator():
+    """The multi-GPU step (nb_comm_init + RCCL all-reduce of forces / r2max / PE) exercised on one
+    GPU with a 1-rank communicator: results must be bit-identical to the comm-less path."""
+    import subprocess
+    import sys
+    script = r'''
+import os, sys, socket
+sys.path.insert(0, os.environ["NB_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+import nbody_cosmological_simulation_amd as nb
+from nbody_cosmological_simulation_amd import runtime, galaxy
+pos, vel, mass = galaxy.create_disk_galaxy(3000, seed=5, device="cpu")
+def run(mode):
+    s = nb.GalaxySimulation(pos, vel, mass, precision_mode=mode)
+    s.run(3)
+    return s.positions.numpy().copy(), s.get_total_energy()
+base = {m: run(m) for m in (nb.PrecisionMode.FLOAT64, nb.PrecisionMode.INT4_SIM)}
+sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+os.environ["NBODY_FORCE_COMM"] = "1"
+runtime.init_distributed(device=0)
+for m, (p0, e0) in base.items():
+    p1, e1 = run(m)
+    assert np.array_equal(p0, p1), m
+    assert e0 == e1, m
+dist.destroy_process_group()
+print("RCCL-1RANK-OK")
+'''
+    env = dict(os.environ, NB_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert "RCCL-1RANK-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+@pytest.mark.parametrize("r", [1, 2, 4])
+@pytest.mark.parametrize("n,d", [(65, 2), (257, 3), (1000, 2), (4099, 2), (6000, 3)])
+def test_pair_symmetric_kernel_vs_oracle(nb, monkeypatch, n, d, r):
+    """The pair-symmetric fp64 kernel (nb_force_sym.hip) forced on for ragged / small sizes."""
+    from oracle import oracle as O
+    if r == 4 and d == 3:
+        pytest.skip("R=4 is compiled for D=2 only")
+    monkeypatch.setenv("NB_SYM", "1")
+    monkeypatch.setenv("NB_SYM_R", str(r))
+    rng = np.random.default_rng(n + d + r)
+    pos = rng.standard_normal((n, d)) * 5
+    vel = rng.standard_normal((n, d)) * 0.05
+    mass = 0.5 + rng.random(n)
+    sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode.FLOAT64)
+    assert relerr(sim.accelerations.numpy(), O.accelerations_f64_fast(pos, mass)) < 1e-13
+    ref = O.OracleSim(pos, vel, mass, "float64")
+    sim.run(3)
+    ref.run(3)
+    assert relerr(sim.positions.numpy(), ref.positions) < 1e-13
+    assert relerr(sim.velocities.numpy(), ref.velocities) < 1e-12
+    # bit-reproducible: same inputs, same bits
+    sim2 = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode.FLOAT64)
+    sim2.run(3)
+    assert np.array_equal(sim.positions.numpy(), sim2.positions.numpy())
