@@ -164,6 +164,9 @@ int nb_comm_init(nb_sim *s, const void *id, int32_t id_bytes);
 /* With NB_FLAG_PROFILE: HIP-event time of the force kernel launches since the last call
  * (events recorded on the handle's own stream).  total_ms / launches = average duration. */
 int nb_kernel_time(nb_sim *s, double *total_ms, int32_t *launches);
+/* Name of the force kernel the last nb_compute_accelerations / nb_step launched (for matching
+ * rocprofv3 rows): "force_sym_f64_kernel", "force_f64_kernel", "force_f32_kernel" or "none". */
+const char *nb_force_kernel_name(nb_sim *s);
 /* Block until all work queued on the handle's stream has finished. */
 int nb_synchronize(nb_sim *s);
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "nb_set_accelerations", "nb_compute_accelerations", "nb_step", "nb_kick_drift", "nb_kick",
     "nb_energy", "nb_quant_debug", "nb_quantize_distance_squared", "nb_quantize_force",
     "nb_grid_quantize", "nb_grid_quantize_safe", "nb_comm_unique_id", "nb_comm_init",
-    "nb_kernel_time", "nb_synchronize", "nb_device_count", "nb_abi_version", "nb_last_error",
+    "nb_kernel_time", "nb_force_kernel_name", "nb_synchronize", "nb_device_count", "nb_abi_version", "nb_last_error",
 ]
 
 
@@ -81,6 +81,7 @@ def lib():
         "nb_comm_unique_id": ([vp, pi32], C.c_int),
         "nb_comm_init": ([vp, vp, i32], C.c_int),
         "nb_kernel_time": ([vp, pdbl, pi32], C.c_int),
+        "nb_force_kernel_name": ([vp], C.c_char_p),
         "nb_synchronize": ([vp], C.c_int),
         "nb_device_count": ([pi32], C.c_int),
         "nb_abi_version": ([], C.c_int),

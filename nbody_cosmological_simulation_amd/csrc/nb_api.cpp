@@ -105,6 +105,9 @@ struct nb_sim {
     size_t scratch_elems = 0;
     double *scalars = nullptr;           // device: [0,1] force min/max, [2] ke, [3] pe
     int16_t *fbins = nullptr;            // n*dim, INT8/INT4 only
+    bool mass_uniform = false;           // all masses equal (checked on the device at upload)
+    double mass_value = 0.0;
+    const char *last_kernel = "none";
     ForceGeom geom{};
     // pair-symmetric fp64 path (nb_force_sym.hip)
     struct SymPlan {
@@ -112,7 +115,8 @@ struct nb_sim {
         int r = 2, tile_b = 128, tiles = 0, np = 0, nwork = 0, nslots = 0, nrows = 0;
         SymWork *work = nullptr;
         int *row_slot0 = nullptr, *row_nslots = nullptr, *row_ord = nullptr;
-        double *packed = nullptr, *rowslab = nullptr, *colslab = nullptr;
+        void *packed = nullptr, *colslab = nullptr;   // storage type of the state (fp32 or fp64)
+        double *rowslab = nullptr;
     } sym;
     ncclComm_t comm = nullptr;
     // profiling
@@ -178,7 +182,7 @@ int build_sym_plan(nb_sim *s)
     sp.r = (c.dim == 2) ? 4 : 2;       // measured on MI355X, N=65536: R=1 3.39 ms, R=2 1.87 ms, R=4 1.47 ms
     if (const char *e = getenv("NB_SYM_R")) {
         const int r = atoi(e);
-        if (r == 1 || r == 2 || (r == 4 && c.dim == 2)) sp.r = r;
+        if ((r == 1 && s->is_f64) || r == 2 || (r == 4 && c.dim == 2)) sp.r = r;
     }
     sp.tile_b = 64 * sp.r;
     sp.tiles = (c.n + sp.tile_b - 1) / sp.tile_b;
@@ -209,8 +213,9 @@ int build_sym_plan(nb_sim *s)
     std::stable_sort(work.begin(), work.end(), [](const SymWork &a, const SymWork &b) {
         return (a.jt_end - a.jt_begin) > (b.jt_end - b.jt_begin);
     });
+    const size_t el = s->is_f64 ? sizeof(double) : sizeof(float);
     const size_t slab = (size_t)c.dim * sp.np * sizeof(double);
-    const size_t col_bytes = slab * (size_t)std::max(nrows, 1);
+    const size_t col_bytes = (size_t)c.dim * sp.np * el * (size_t)std::max(nrows, 1);
     if (col_bytes > (size_t)48 << 30) return NB_OK;       // fall back to the one-sided kernel
     sp.nwork = (int)work.size();
     sp.nslots = slots;
@@ -220,7 +225,7 @@ int build_sym_plan(nb_sim *s)
     HIPCHK(hipMalloc((void **)&sp.row_slot0, T * sizeof(int)));
     HIPCHK(hipMalloc((void **)&sp.row_nslots, T * sizeof(int)));
     HIPCHK(hipMalloc((void **)&sp.row_ord, T * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&sp.packed, (size_t)(c.dim + 1) * sp.np * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&sp.packed, (size_t)(c.dim + 1) * sp.np * el));
     HIPCHK(hipMalloc((void **)&sp.rowslab, slab * (size_t)std::max(slots, 1)));
     HIPCHK(hipMalloc((void **)&sp.colslab, col_bytes));
     HIPCHK(hipMemcpy(sp.work, work.data(), work.size() * sizeof(SymWork), hipMemcpyHostToDevice));
@@ -258,7 +263,7 @@ int ensure_storage(nb_sim *s, bool f64)
     HIPCHK(hipMemsetAsync(s->scalars, 0, 8 * sizeof(double), s->stream));
     if (force_quant_mode(s->cfg)) HIPCHK(hipMalloc((void **)&s->fbins, cnt * sizeof(int16_t)));
     HIPCHK(hipMemsetAsync(s->acc, 0, cnt * el, s->stream));
-    if (f64) if (int rc = build_sym_plan(s)) return rc;
+    if (int rc = build_sym_plan(s)) return rc;
     s->have_storage = true;
     return NB_OK;
 }
@@ -344,7 +349,7 @@ int prof_end(nb_sim *s, int slot)
 }
 
 // one evaluation of simulation.py:74-118; optionally followed by the closing half kick (:141)
-int force_eval(nb_sim *s, bool do_kick)
+int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false)
 {
     if (!s->have_pos || !s->have_mass) return fail(NB_ERR_INVALID, "positions and masses must be set first");
     const nb_config &c = s->cfg;
@@ -358,25 +363,30 @@ int force_eval(nb_sim *s, bool do_kick)
     if (multi && !s->comm) return fail(NB_ERR_COMM, "nranks > 1 but nb_comm_init was not called");
     if (no_comm && c.nranks > 1 && do_kick) return fail(NB_ERR_INVALID, "NB_FLAG_NO_COMM handles cannot step");
     int slot;
-    bool used_sym = false;
+    bool used_sym = false, sym_uniform = false;
 
     if (s->is_f64) {
         if (c.mode != NB_FLOAT64)
             return fail(NB_ERR_UNSUPPORTED, "fp64 state with a non-FLOAT64 precision mode is not implemented yet");
         const int pa_f32 = (s->logical[0] == NB_F32);
         used_sym = s->sym.enabled && !pa_f32;
+        sym_uniform = s->mass_uniform;
         if (used_sym) {
             const auto &sp = s->sym;
-            HIPCHK(nb_launch_pack_f64((const double *)s->pos, (const double *)s->mass, sp.packed, c.n, sp.np, c.dim,
+            if (!packed_ready)
+                HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, 1, 0, 0.0, 0.0,
                                       c.G, s->stream));
             if (int rc = prof_begin(s, &slot)) return rc;
-            HIPCHK(nb_launch_force_sym_f64(sp.packed, sp.work, sp.nwork, sp.rowslab, sp.colslab, sp.np, c.dim, sp.r,
-                                           c.softening_sq, s->stream));
+            HIPCHK(nb_launch_force_sym_f64((const double *)sp.packed, sp.work, sp.nwork, sp.rowslab,
+                                           (double *)sp.colslab, sp.np, c.dim, sp.r, s->mass_uniform, c.softening_sq,
+                                           s->stream));
+            s->last_kernel = "force_sym_f64_kernel";
             if (int rc = prof_end(s, slot)) return rc;
         } else {
             if (int rc = prof_begin(s, &slot)) return rc;
             HIPCHK(nb_launch_force_f64((const double *)s->pos, (const double *)s->mass, s->partial, s->geom, c.dim,
                                        pa_f32, c.G, c.softening_sq, s->stream));
+            s->last_kernel = "force_f64_kernel";
             if (int rc = prof_end(s, slot)) return rc;
         }
     } else {
@@ -403,18 +413,38 @@ int force_eval(nb_sim *s, bool do_kick)
                                          s->stream));
             HIPCHK(nb_launch_grid_tables(s->tab, L, (float)c.G, eps2, 0.01f, s->stream));
         }
-        if (int rc = prof_begin(s, &slot)) return rc;
-        HIPCHK(nb_launch_force_f32((const float *)s->pos, (const float *)s->mass, s->partial, s->geom, c.dim, hook,
-                                   (float)c.G, eps2, s->tab, s->stream));
-        if (int rc = prof_end(s, slot)) return rc;
+        used_sym = s->sym.enabled;
+        if (used_sym) {
+            const auto &sp = s->sym;
+            // grid LUT already carries G (simulation.py:101), so the packed factor is the bare mass there
+            sym_uniform = s->mass_uniform && hook != HOOK_GRID;
+            const double gfac = (hook == HOOK_GRID) ? 1.0 : (double)(float)c.G;
+            if (!packed_ready || hook == HOOK_GRID)
+                HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, 0, 0, 0.0, 0.0,
+                                      gfac, s->stream));
+            if (int rc = prof_begin(s, &slot)) return rc;
+            HIPCHK(nb_launch_force_sym_f32((const float *)sp.packed, sp.work, sp.nwork, sp.rowslab,
+                                           (float *)sp.colslab, sp.np, c.dim, sp.r, sym_uniform, hook, eps2, s->tab,
+                                           (float)c.G, s->stream));
+            s->last_kernel = "force_sym_f32_kernel";
+            if (int rc = prof_end(s, slot)) return rc;
+        } else {
+            if (int rc = prof_begin(s, &slot)) return rc;
+            HIPCHK(nb_launch_force_f32((const float *)s->pos, (const float *)s->mass, s->partial, s->geom, c.dim, hook,
+                                       (float)c.G, eps2, s->tab, s->stream));
+            s->last_kernel = "force_f32_kernel";
+            if (int rc = prof_end(s, slot)) return rc;
+        }
     }
 
     const bool fuse_kick = do_kick && !multi && !fq;
     if (used_sym) {
         const auto &sp = s->sym;
-        HIPCHK(nb_launch_reduce_sym_f64(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.row_ord, sp.tile_b,
-                                        c.n, sp.np, c.dim, (double *)s->acc, (double *)s->vel, half_dt, fuse_kick,
-                                        s->stream));
+        // uniform-mass kernels leave out the mass factor: G*m in T arithmetic (fp32: (float)G * m)
+        double scale = 1.0;
+        if (sym_uniform) scale = s->is_f64 ? c.G * s->mass_value : (double)((float)c.G * (float)s->mass_value);
+        HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.row_ord, sp.tile_b, c.n,
+                                    sp.np, c.dim, s->is_f64, scale, s->acc, s->vel, half_dt, fuse_kick, s->stream));
     } else {
         HIPCHK(nb_launch_reduce(s->partial, s->geom.nchunks, cnt, s->acc, s->is_f64, s->vel, half_dt, fuse_kick,
                                 s->stream));
@@ -525,7 +555,18 @@ int nb_set_state(nb_sim *s, const void *pos, const void *vel, const void *mass, 
     if (dtype == NB_F64 && !s->is_f64) return fail(NB_ERR_UNSUPPORTED, "cannot upload fp64 data into fp32 state");
     if (pos) { if (int rc = upload(s, pos, dtype, on_device, s->pos, nd(s))) return rc; s->logical[0] = dtype; s->have_pos = true; }
     if (vel) { if (int rc = upload(s, vel, dtype, on_device, s->vel, nd(s))) return rc; s->logical[1] = dtype; s->have_vel = true; }
-    if (mass) { if (int rc = upload(s, mass, dtype, on_device, s->mass, s->cfg.n)) return rc; s->logical[2] = dtype; s->have_mass = true; }
+    if (mass) {
+        if (int rc = upload(s, mass, dtype, on_device, s->mass, s->cfg.n)) return rc;
+        s->logical[2] = dtype;
+        s->have_mass = true;
+        // uniform-mass detection (one min/max pass on the device per upload, not per step)
+        double mm[2];
+        HIPCHK(nb_launch_minmax_generic(s->mass, s->is_f64, s->cfg.n, 0, 0.0, s->scalars + 4, s->stream));
+        HIPCHK(hipMemcpyAsync(mm, s->scalars + 4, sizeof mm, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        s->mass_uniform = (mm[0] == mm[1]) && std::isfinite(mm[0]) && !getenv("NB_NO_UNIFORM");
+        s->mass_value = mm[0];
+    }
     return NB_OK;
 }
 
@@ -597,10 +638,19 @@ int nb_step(nb_sim *s, int32_t nsteps)
     if (!s->have_acc) return fail(NB_ERR_INVALID, "no accelerations yet: call nb_compute_accelerations first");
     DeviceGuard guard(s->cfg.device);
     for (int t = 0; t < nsteps; ++t) {
-        HIPCHK(nb_launch_kick_drift(s->pos, s->vel, s->acc, s->cfg.dt / 2, s->cfg.dt, nd(s), s->is_f64, s->stream));
+        // opening kick + drift; on the pair-symmetric path the repack rides in the same launch
+        const int sdt = s->is_f64 ? NB_F64 : NB_F32;
+        const bool fuse_pack = s->sym.enabled && s->logical[0] == sdt && s->logical[1] == sdt &&
+                               s->logical[3] == sdt && !grid_mode(s->cfg.mode);
+        if (fuse_pack)
+            HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, s->sym.packed, s->cfg.n, s->sym.np, s->cfg.dim,
+                                  s->is_f64, 1, s->cfg.dt / 2, s->cfg.dt, s->is_f64 ? s->cfg.G : (double)(float)s->cfg.G,
+                                  s->stream));
+        else
+            HIPCHK(nb_launch_kick_drift(s->pos, s->vel, s->acc, s->cfg.dt / 2, s->cfg.dt, nd(s), s->is_f64, s->stream));
         s->logical[1] = promote(s->logical[1], s->logical[3]);
         s->logical[0] = promote(s->logical[0], s->logical[1]);
-        if (int rc = force_eval(s, true)) return rc;
+        if (int rc = force_eval(s, true, fuse_pack)) return rc;
         s->logical[1] = promote(s->logical[1], s->logical[3]);
     }
     return NB_OK;
@@ -819,6 +869,8 @@ int nb_kernel_time(nb_sim *s, double *total_ms, int32_t *launches)
     s->prof_launches = 0;
     return NB_OK;
 }
+
+const char *nb_force_kernel_name(nb_sim *s) { return s ? s->last_kernel : "none"; }
 
 int nb_synchronize(nb_sim *s)
 {

@@ -243,6 +243,8 @@ force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
                     if (HOOK == HOOK_BF16) q = round_bf16(r2);
                     if (HOOK == HOOK_F16) q = round_f16(r2);
                     wq = inv_r3_f32(q) * G;
+                    // fp16 overflow: q = +inf -> pow = inf -> 1/inf = 0 upstream (rsq-based form gives NaN)
+                    if (HOOK == HOOK_F16) wq = (q == __builtin_inff()) ? 0.0f : wq;
                 }
                 const float w = wq * mj;                                // simulation.py:105
 #pragma unroll

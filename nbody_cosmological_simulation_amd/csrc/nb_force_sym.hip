@@ -1,27 +1,30 @@
-// nb_force_sym.hip -- pair-symmetric all-pairs force kernel for gfx950 (fp64 state).
+// nb_force_sym.hip -- pair-symmetric all-pairs force kernels for gfx950 (fp64 and fp32 state).
 //
-// Same mathematics as force_f64_kernel (reference simulation.py:74-118, FLOAT64 mode), but
-// every UNORDERED pair {a, b} is evaluated once and applied to both particles
-// (a_a += G m_b w d,  a_b -= G m_a w d), which halves the q^(-3/2) evaluations -- the dominant
-// cost of this VALU-bound kernel (DESIGN.md "instruction budget": 16 fp64 ops per unordered
-// pair instead of 13 per ordered pair).  The reference treats the summation order as free
-// (SURVEY.md section 2, row 20), so the result is the same sum in a different, FIXED order.
+// Same mathematics as the one-sided kernels of nb_force.hip (reference simulation.py:74-118 with
+// the hooks of quantization.py:21-71), but every UNORDERED pair {a, b} is evaluated once and
+// applied to both particles (a_a += m_b w d,  a_b -= m_a w d): r2 and the hook are symmetric in
+// (a, b) -- d_ab = -d_ba exactly, also in fp32 without FMA -- so the quantised distance and its
+// bin are the same for both directions.  This halves the q^(-3/2) evaluations, the dominant cost
+// of this VALU-bound path (DESIGN.md "instruction budget").  The reference treats the summation
+// order as free; here it is a different but FIXED order.
 //
-// Scheme (no LDS, no barriers in the pair loop):
+// Scheme (no LDS staging, no barrier in the pair loop):
 //   particles are cut into tiles of B = 64*R; a wavefront keeps one target tile I in registers
 //   (R particles per lane) for its whole life and walks source tiles J >= I.  The J tile is held
 //   one particle-set per lane too, together with ITS accumulators; after each of 64 steps the J
-//   data and the J accumulators rotate by one lane (ds_bpermute: the LDS crossbar, not the
-//   VALU), so every lane meets every J particle once and the accumulators return home.
+//   data and the J accumulators rotate by one lane (ds_bpermute_b32: the LDS crossbar, no VALU
+//   cycles), so every lane meets every J particle once and the accumulators return home.
 //   J == I (diagonal tile) is evaluated one-sided, so each ordered pair is counted once.
 //   Outputs go to per-(row chunk) and per-(row) slabs that reduce_sym_kernel adds in a fixed
 //   order: no atomics, run-to-run bit-identical.
 #include "nb_internal.h"
 
+#include <type_traits>
+
 namespace {
 
-template <typename V>
-__device__ __forceinline__ V rot1(V v, int src_lane_addr);
+template <typename T>
+__device__ __forceinline__ T rot1(T v, int addr);
 
 template <>
 __device__ __forceinline__ double rot1<double>(double v, int addr)
@@ -31,10 +34,16 @@ __device__ __forceinline__ double rot1<double>(double v, int addr)
     const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+template <>
+__device__ __forceinline__ float rot1<float>(float v, int addr)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
+}
 
-// s = q^(-3/2) without any mass factor (see inv_r3_f64 in nb_force.hip for the derivation).
-// c15 / c1875 hold 1.5 and 1.875 in registers chosen by the caller: as literals the compiler
-// re-materialises 1.5 with two v_mov per pair (v_fmac needs it in the destination).
+// q^(-3/2) without any mass factor.
+// fp64: v_rsq_f64 seed (2^-24) + second-order correction, see inv_r3_f64 in nb_force.hip.
+//       c15 / c1875 hold 1.5 and 1.875 in registers chosen by the caller: as literals the
+//       compiler re-materialises 1.5 with two v_mov per pair (v_fmac needs it in the destination).
 __device__ __forceinline__ double inv_r3_sym(double q, double c15, double c1875)
 {
     const double y0 = __builtin_amdgcn_rsq(q);
@@ -45,36 +54,90 @@ __device__ __forceinline__ double inv_r3_sym(double q, double c15, double c1875)
     const double ce = c * e;
     return __builtin_fma(v, ce, v);
 }
+// fp32: v_rsq_f32 seed (1 ulp) + first-order correction of the cube: y0^3 (1 + 1.5 e), residual
+//       ~2 e^2 < 1e-13, leaving only the ~1.5 ulp of the three roundings.
+__device__ __forceinline__ float inv_r3_sym(float q, float c15, float)
+{
+    const float y0 = __builtin_amdgcn_rsqf(q);
+    const float y02 = y0 * y0;
+    const float e = __builtin_fmaf(-q, y02, 1.0f);
+    const float v = y0 * y02;
+    const float ve = v * e;
+    return __builtin_fmaf(ve, c15, v);
+}
+
+template <int LP>
+__device__ __forceinline__ int grid_bin_lookup(const float *thr, float r2)
+{
+    int k = 0;
+#pragma unroll
+    for (int step = LP / 2; step >= 1; step >>= 1)
+        k += (thr[k + step] <= r2) ? step : 0;
+    return k;
+}
 
 // One tile-vs-tile sweep: 64 steps, R*R pairs per lane per step, J data rotating by one lane.
-// DIAG: J is the target tile itself -> one-sided (each ordered pair once, mirror images dropped).
-template <int D, int R, bool DIAG>
-__device__ __forceinline__ void sweep(const double (&xi)[R][D], const double (&gi)[R], double (&ai)[R][D],
-                                      double (&xj)[R][D], double (&gj)[R], double (&aj)[R][D], double eps2,
-                                      int rot_addr)
+// DIAG:    J is the target tile itself -> one-sided (each ordered pair once, mirrors dropped).
+// UNIFORM: all masses equal -> the mass factor is applied once to the finished sums
+//          (reduce_sym_kernel), saving both mass multiplies and the rotation of the masses.
+// HOOK:    precision hook applied to the fp32 r2 (HOOK_NONE for fp64).
+template <typename T, int D, int R, bool DIAG, bool UNIFORM, int HOOK>
+__device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (&ai)[R][D], T (&xj)[R][D],
+                                      T (&gj)[R], T (&aj)[R][D], T eps2, int rot_addr, const float *s_thr,
+                                      const float *s_lut, bool degenerate, float gfac)
 {
-    double c15 = 1.5, c1875 = 1.875;
-    asm volatile("" : "+v"(c15), "+s"(c1875));     // opaque: keep them in a VGPR / SGPR pair
+    T c15 = (T)1.5, c1875 = (T)1.875;
+    if constexpr (std::is_same_v<T, double>) asm volatile("" : "+v"(c15), "+s"(c1875));
 #pragma unroll 1
     for (int s = 0; s < 64; ++s) {
 #pragma unroll
         for (int ri = 0; ri < R; ++ri) {
 #pragma unroll
             for (int rj = 0; rj < R; ++rj) {
-                double d[D];
+                T d[D];
+                T w;
+                if constexpr (std::is_same_v<T, double>) {
 #pragma unroll
-                for (int k = 0; k < D; ++k) d[k] = xj[rj][k] - xi[ri][k];
-                double q = __builtin_fma(d[D - 1], d[D - 1], eps2);
+                    for (int k = 0; k < D; ++k) d[k] = xj[rj][k] - xi[ri][k];
+                    double q = __builtin_fma(d[D - 1], d[D - 1], eps2);
 #pragma unroll
-                for (int k = D - 2; k >= 0; --k) q = __builtin_fma(d[k], d[k], q);
-                const double w = inv_r3_sym(q, c15, c1875);
-                const double wj = w * gj[rj];
+                    for (int k = D - 2; k >= 0; --k) q = __builtin_fma(d[k], d[k], q);
+                    w = inv_r3_sym(q, c15, c1875);
+                } else {
+                    // reference op order, one rounding per op, no FMA (bit-identical r2)
 #pragma unroll
-                for (int k = 0; k < D; ++k) ai[ri][k] = __builtin_fma(wj, d[k], ai[ri][k]);
+                    for (int k = 0; k < D; ++k) d[k] = __fsub_rn(xj[rj][k], xi[ri][k]);
+                    float r2 = __fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1]));
+                    if (D == 3) r2 = __fadd_rn(r2, __fmul_rn(d[2], d[2]));
+                    r2 = __fadd_rn(r2, eps2);
+                    if (HOOK == HOOK_GRID) {
+                        if (!degenerate) {
+                            w = s_lut[grid_bin_lookup<NB_MAX_LUT>(s_thr, r2)];   // (1/q^1.5)*G
+                        } else {
+                            w = inv_r3_sym((r2 < 0.01f) ? 0.01f : r2, c15, c1875) * gfac;
+                        }
+                    } else {
+                        float q = r2;
+                        if (HOOK == HOOK_BF16) q = (float)(__bf16)r2;
+                        if (HOOK == HOOK_F16) q = (float)(_Float16)r2;
+                        w = inv_r3_sym(q, c15, c1875);
+                        // fp16 overflow: q = +inf -> pow = inf -> 1/inf = 0 upstream (rsq-based form gives NaN)
+                        if (HOOK == HOOK_F16) w = (q == __builtin_inff()) ? 0.0f : w;
+                    }
+                }
+                const T wj = UNIFORM ? w : w * gj[rj];
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    if constexpr (std::is_same_v<T, double>) ai[ri][k] = __builtin_fma(wj, d[k], ai[ri][k]);
+                    else ai[ri][k] = __builtin_fmaf(wj, d[k], ai[ri][k]);
+                }
                 if (!DIAG) {
-                    const double wi = w * gi[ri];
+                    const T wi = UNIFORM ? w : w * gi[ri];
 #pragma unroll
-                    for (int k = 0; k < D; ++k) aj[rj][k] = __builtin_fma(-wi, d[k], aj[rj][k]);
+                    for (int k = 0; k < D; ++k) {
+                        if constexpr (std::is_same_v<T, double>) aj[rj][k] = __builtin_fma(-wi, d[k], aj[rj][k]);
+                        else aj[rj][k] = __builtin_fmaf(-wi, d[k], aj[rj][k]);
+                    }
                 }
             }
         }
@@ -82,71 +145,91 @@ __device__ __forceinline__ void sweep(const double (&xi)[R][D], const double (&g
         for (int r = 0; r < R; ++r) {
 #pragma unroll
             for (int k = 0; k < D; ++k) {
-                xj[r][k] = rot1<double>(xj[r][k], rot_addr);
-                if (!DIAG) aj[r][k] = rot1<double>(aj[r][k], rot_addr);
+                xj[r][k] = rot1<T>(xj[r][k], rot_addr);
+                if (!DIAG) aj[r][k] = rot1<T>(aj[r][k], rot_addr);
             }
-            gj[r] = rot1<double>(gj[r], rot_addr);
+            if (!UNIFORM) gj[r] = rot1<T>(gj[r], rot_addr);
         }
     }
 }
 
-template <int D, int R>
+// T = double: FLOAT64 mode on fp64 state.  T = float: every fp32-state mode (HOOK selects it).
+// packed  [D+1][NP] of T : x, y, (z), mass factor (G*m, or m for HOOK_GRID whose LUT carries G);
+//                          padding particles sit far away (see pack_kernel).
+// rowslab [slot][D][NP] fp64, colslab [row][D][NP] of T.
+template <typename T, int D, int R, bool UNIFORM, int HOOK>
 __global__ void __launch_bounds__(NB_BLOCK)
-force_sym_f64_kernel(const double *__restrict__ packed,   // [D+1][NP]: x, y, (z), G*m ; padded with m = 0
-                     const SymWork *__restrict__ work, double *__restrict__ rowslab,
-                     double *__restrict__ colslab, int np, double eps2)
+force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work, double *__restrict__ rowslab,
+                 T *__restrict__ colslab, int np, T eps2, const GridTables *__restrict__ tab, float gfac)
 {
     constexpr int B = 64 * R;
+    constexpr bool F32 = std::is_same_v<T, float>;
     __shared__ double s_ai[NB_BLOCK / 64][R][D][64];
+    __shared__ float s_thr[HOOK == HOOK_GRID ? NB_MAX_LUT : 1];
+    __shared__ float s_lut[HOOK == HOOK_GRID ? NB_MAX_LUT : 1];
 
     const SymWork wk = work[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rot_addr = ((lane + 1) & 63) << 2;
+    bool degenerate = false;
+    if (HOOK == HOOK_GRID) {
+        for (int k = threadIdx.x; k < NB_MAX_LUT; k += NB_BLOCK) {
+            s_thr[k] = (k < tab->levels) ? tab->thr[k] : __builtin_inff();
+            s_lut[k] = (k < tab->levels) ? tab->lut[k] : 0.0f;
+        }
+        degenerate = tab->degenerate != 0;
+        __syncthreads();
+    }
 
-    double xi[R][D], gi[R], ai[R][D];
+    T xi[R][D], gi[R];
+    double ai_sum[R][D];      // fp64 running sums over the whole chunk (fp32: folded per tile)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int p = wk.tile_i * B + r * 64 + lane;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             xi[r][k] = packed[(size_t)k * np + p];
-            ai[r][k] = 0.0;
+            ai_sum[r][k] = 0.0;
         }
-        gi[r] = packed[(size_t)D * np + p];
+        gi[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
     }
 
     for (int J = wk.jt_begin + wave; J < wk.jt_end; J += NB_BLOCK / 64) {
-        double xj[R][D], gj[R], aj[R][D];
+        T xj[R][D], gj[R], aj[R][D], ai[R][D];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int p = J * B + r * 64 + lane;
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 xj[r][k] = packed[(size_t)k * np + p];
-                aj[r][k] = 0.0;
+                aj[r][k] = (T)0;
+                ai[r][k] = F32 ? (T)0 : (T)ai_sum[r][k];
             }
-            gj[r] = packed[(size_t)D * np + p];
+            gj[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
         }
         if (J == wk.tile_i) {                   // wave-uniform
-            sweep<D, R, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr);
+            sweep<T, D, R, true, UNIFORM, HOOK>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, s_thr, s_lut, degenerate, gfac);
         } else {
-            sweep<D, R, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr);
+            sweep<T, D, R, false, UNIFORM, HOOK>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, s_thr, s_lut, degenerate, gfac);
             // column contributions of row I to the particles of tile J (accumulators are home again)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int p = J * B + r * 64 + lane;
 #pragma unroll
-                for (int k = 0; k < D; ++k)
-                    colslab[((size_t)wk.row_ord * D + k) * np + p] = aj[r][k];
+                for (int k = 0; k < D; ++k) colslab[((size_t)wk.row_ord * D + k) * np + p] = aj[r][k];
             }
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < D; ++k) ai_sum[r][k] = F32 ? ai_sum[r][k] + (double)ai[r][k] : (double)ai[r][k];
     }
 
     // combine the four waves' row sums in a fixed order and write one slab slot per workgroup
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int k = 0; k < D; ++k) s_ai[wave][r][k][lane] = ai[r][k];
+        for (int k = 0; k < D; ++k) s_ai[wave][r][k][lane] = ai_sum[r][k];
     __syncthreads();
     for (int idx = threadIdx.x; idx < R * D * 64; idx += NB_BLOCK) {
         const int l = idx & 63, rk = idx >> 6;
@@ -159,93 +242,174 @@ force_sym_f64_kernel(const double *__restrict__ packed,   // [D+1][NP]: x, y, (z
     }
 }
 
-// x, y, (z), G*m as padded component arrays
-template <int D>
+// Padding particles sit at PAD in every coordinate: r^2 stays finite, y0^3 underflows to exactly
+// 0 (fp64: r2 ~ 1e300, y0^3 ~ 1e-450; fp32: r2 ~ 1e36, y0^3 ~ 1e-54), so they contribute exactly
+// nothing whatever their mass; in grid modes they fall into the last bin and carry mass 0.
+template <typename T> __device__ __forceinline__ T pad_coord();
+template <> __device__ __forceinline__ double pad_coord<double>() { return 1e150; }
+template <> __device__ __forceinline__ float pad_coord<float>() { return 1e18f; }
+
+template <typename T> __device__ __forceinline__ T axpy_rn(T a, T b, T s);
+template <> __device__ __forceinline__ double axpy_rn<double>(double a, double b, double s) { return __dadd_rn(a, __dmul_rn(b, s)); }
+template <> __device__ __forceinline__ float axpy_rn<float>(float a, float b, float s) { return __fadd_rn(a, __fmul_rn(b, s)); }
+
+// x, y, (z), mass factor as padded component arrays; with KICK the opening half of a step rides
+// along: v += a*(dt/2); x += v*dt (simulation.py:132,135, separate mul/add roundings like torch).
+template <typename T, int D, bool KICK>
 __global__ void __launch_bounds__(NB_BLOCK)
-pack_kernel(const double *__restrict__ pos, const double *__restrict__ mass, double *__restrict__ packed, int n,
-            int np, double G)
+pack_kernel(T *__restrict__ pos, T *__restrict__ vel, const T *__restrict__ acc, const T *__restrict__ mass,
+            T *__restrict__ packed, int n, int np, T half_dt, T dt, T gfac)
 {
     const int p = blockIdx.x * NB_BLOCK + threadIdx.x;
     if (p >= np) return;
-    const bool real = p < n;
+    if (p < n) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) packed[(size_t)k * np + p] = real ? pos[(size_t)p * D + k] : 0.0;
-    packed[(size_t)D * np + p] = real ? G * mass[p] : 0.0;
+        for (int k = 0; k < D; ++k) {
+            const size_t idx = (size_t)p * D + k;
+            T x = pos[idx];
+            if (KICK) {
+                const T v = axpy_rn<T>(vel[idx], acc[idx], half_dt);
+                x = axpy_rn<T>(x, v, dt);
+                vel[idx] = v;
+                pos[idx] = x;
+            }
+            packed[(size_t)k * np + p] = x;
+        }
+        packed[(size_t)D * np + p] = gfac * mass[p];
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) packed[(size_t)k * np + p] = pad_coord<T>();
+        packed[(size_t)D * np + p] = (T)0;
+    }
 }
 
 // acc[p] = sum of the row slots of p's tile + sum over rows I < tile(p) of the column slabs,
-// always in the same order.  Optionally fuses the closing half kick (simulation.py:141).
-template <int D>
+// always in the same order.  Block = 64 particles x 4 waves: wave g adds rows I = g, g+4, ...
+// (four loads in flight per lane), the four partial sums are combined in the order g = 0..3
+// through LDS -> still one fixed summation tree.  Optionally fuses the closing half kick
+// (simulation.py:141) and applies the uniform-mass factor.
+template <typename T, int D>
 __global__ void __launch_bounds__(NB_BLOCK)
-reduce_sym_kernel(const double *__restrict__ rowslab, const double *__restrict__ colslab,
+reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ colslab,
                   const int *__restrict__ row_slot0, const int *__restrict__ row_nslots,
-                  const int *__restrict__ row_ord, int tile_b, int n, int np, double *__restrict__ acc,
-                  double *__restrict__ vel, double half_dt, int do_kick)
+                  const int *__restrict__ row_ord, int tile_b, int n, int np, double scale, T *__restrict__ acc,
+                  T *__restrict__ vel, T half_dt, int do_kick)
 {
-    const int p = blockIdx.x * NB_BLOCK + threadIdx.x;
-    if (p >= n) return;
-    const int J = p / tile_b;
+    __shared__ double s_part[NB_BLOCK / 64][D][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    const int pc = p < n ? p : n - 1;
+    const int J = pc / tile_b;
     double s[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) s[k] = 0.0;
-    const int s0 = row_slot0[J], ns = row_nslots[J];
-    for (int c = 0; c < ns; ++c)
+    if (g == 0) {
+        const int s0 = row_slot0[J], ns = row_nslots[J];
+        for (int c = 0; c < ns; ++c)
 #pragma unroll
-        for (int k = 0; k < D; ++k) s[k] += rowslab[((size_t)(s0 + c) * D + k) * np + p];
+            for (int k = 0; k < D; ++k) s[k] += rowslab[((size_t)(s0 + c) * D + k) * np + pc];
+    }
 #pragma unroll 4
-    for (int I = 0; I < J; ++I) {
+    for (int I = g; I < J; I += NB_BLOCK / 64) {
         const int ord = row_ord[I];
         if (ord >= 0) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) s[k] += colslab[((size_t)ord * D + k) * np + p];
+            for (int k = 0; k < D; ++k) s[k] += (double)colslab[((size_t)ord * D + k) * np + pc];
         }
     }
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-        const size_t idx = (size_t)p * D + k;
-        acc[idx] = s[k];
-        if (do_kick) vel[idx] = __dadd_rn(vel[idx], __dmul_rn(s[k], half_dt));
+    for (int k = 0; k < D; ++k) s_part[g][k][lane] = s[k];
+    __syncthreads();
+    if (g == 0 && p < n) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double t = s_part[0][k][lane];
+#pragma unroll
+            for (int w = 1; w < NB_BLOCK / 64; ++w) t += s_part[w][k][lane];
+            const size_t idx = (size_t)p * D + k;
+            const T a = (T)(t * scale);            // scale = mass factor of the uniform kernel, else 1
+            acc[idx] = a;
+            if (do_kick) vel[idx] = axpy_rn<T>(vel[idx], a, half_dt);
+        }
     }
+}
+
+template <typename T, int D, int R, int HOOK>
+hipError_t launch_sym_u(const T *packed, const SymWork *work, int nwork, double *rowslab, T *colslab, int np,
+                        int uniform, T eps2, const GridTables *tab, float gfac, hipStream_t st)
+{
+    if (uniform)
+        hipLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, packed, work,
+                           rowslab, colslab, np, eps2, tab, gfac);
+    else
+        hipLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, packed, work,
+                           rowslab, colslab, np, eps2, tab, gfac);
+    return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t nb_launch_pack_f64(const double *pos, const double *mass, double *packed, int n, int np, int dim,
-                              double G, hipStream_t st)
+hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mass, void *packed, int n, int np,
+                          int dim, int is_f64, int kick, double half_dt, double dt, double gfac, hipStream_t st)
 {
     const int grid = (np + NB_BLOCK - 1) / NB_BLOCK;
-    if (dim == 2) hipLaunchKernelGGL((pack_kernel<2>), dim3(grid), dim3(NB_BLOCK), 0, st, pos, mass, packed, n, np, G);
-    else if (dim == 3) hipLaunchKernelGGL((pack_kernel<3>), dim3(grid), dim3(NB_BLOCK), 0, st, pos, mass, packed, n, np, G);
-    else return hipErrorInvalidValue;
+#define NB_PACK(TT, DD, KK) \
+    hipLaunchKernelGGL((pack_kernel<TT, DD, KK>), dim3(grid), dim3(NB_BLOCK), 0, st, (TT *)pos, (TT *)vel, \
+                       (const TT *)acc, (const TT *)mass, (TT *)packed, n, np, (TT)half_dt, (TT)dt, (TT)gfac)
+    if (dim != 2 && dim != 3) return hipErrorInvalidValue;
+    if (is_f64) {
+        if (dim == 2) { if (kick) NB_PACK(double, 2, true); else NB_PACK(double, 2, false); }
+        else          { if (kick) NB_PACK(double, 3, true); else NB_PACK(double, 3, false); }
+    } else {
+        if (dim == 2) { if (kick) NB_PACK(float, 2, true); else NB_PACK(float, 2, false); }
+        else          { if (kick) NB_PACK(float, 3, true); else NB_PACK(float, 3, false); }
+    }
+#undef NB_PACK
     return hipGetLastError();
 }
 
 hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, int nwork, double *rowslab,
-                                   double *colslab, int np, int dim, int r, double eps2, hipStream_t st)
+                                   double *colslab, int np, int dim, int r, int uniform, double eps2, hipStream_t st)
 {
-#define NB_SYM(DD, RR) \
-    hipLaunchKernelGGL((force_sym_f64_kernel<DD, RR>), dim3(nwork), dim3(NB_BLOCK), 0, st, packed, work, rowslab, colslab, np, eps2)
-    if (dim == 2 && r == 1) NB_SYM(2, 1);
-    else if (dim == 2 && r == 2) NB_SYM(2, 2);
-    else if (dim == 2 && r == 4) NB_SYM(2, 4);
-    else if (dim == 3 && r == 1) NB_SYM(3, 1);
-    else if (dim == 3 && r == 2) NB_SYM(3, 2);
-    else return hipErrorInvalidValue;
-#undef NB_SYM
-    return hipGetLastError();
+    if (dim == 2 && r == 1) return launch_sym_u<double, 2, 1, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st);
+    if (dim == 2 && r == 2) return launch_sym_u<double, 2, 2, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st);
+    if (dim == 2 && r == 4) return launch_sym_u<double, 2, 4, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st);
+    if (dim == 3 && r == 1) return launch_sym_u<double, 3, 1, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st);
+    if (dim == 3 && r == 2) return launch_sym_u<double, 3, 2, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st);
+    return hipErrorInvalidValue;
 }
 
-hipError_t nb_launch_reduce_sym_f64(const double *rowslab, const double *colslab, const int *row_slot0,
-                                    const int *row_nslots, const int *row_ord, int tile_b, int n, int np, int dim,
-                                    double *acc, double *vel, double half_dt, int do_kick, hipStream_t st)
+hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int nwork, double *rowslab,
+                                   float *colslab, int np, int dim, int r, int uniform, int hook, float eps2,
+                                   const GridTables *tab, float G, hipStream_t st)
 {
-    const int grid = (n + NB_BLOCK - 1) / NB_BLOCK;
-    if (dim == 2)
-        hipLaunchKernelGGL((reduce_sym_kernel<2>), dim3(grid), dim3(NB_BLOCK), 0, st, rowslab, colslab, row_slot0,
-                           row_nslots, row_ord, tile_b, n, np, acc, vel, half_dt, do_kick);
-    else if (dim == 3)
-        hipLaunchKernelGGL((reduce_sym_kernel<3>), dim3(grid), dim3(NB_BLOCK), 0, st, rowslab, colslab, row_slot0,
-                           row_nslots, row_ord, tile_b, n, np, acc, vel, half_dt, do_kick);
-    else return hipErrorInvalidValue;
+#define NB_SYM32(DD, RR)                                                                                              \
+    switch (hook) {                                                                                                   \
+    case HOOK_NONE: return launch_sym_u<float, DD, RR, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st); \
+    case HOOK_BF16: return launch_sym_u<float, DD, RR, HOOK_BF16>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st); \
+    case HOOK_F16: return launch_sym_u<float, DD, RR, HOOK_F16>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st);   \
+    case HOOK_GRID: return launch_sym_u<float, DD, RR, HOOK_GRID>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st); \
+    default: return hipErrorInvalidValue;                                                                             \
+    }
+    if (dim == 2 && r == 2) { NB_SYM32(2, 2) }
+    if (dim == 2 && r == 4) { NB_SYM32(2, 4) }
+    if (dim == 3 && r == 2) { NB_SYM32(3, 2) }
+#undef NB_SYM32
+    return hipErrorInvalidValue;
+}
+
+hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
+                                const int *row_nslots, const int *row_ord, int tile_b, int n, int np, int dim,
+                                int is_f64, double scale, void *acc, void *vel, double half_dt, int do_kick,
+                                hipStream_t st)
+{
+    const int grid = (n + 63) / 64;
+#define NB_RED(TT, DD) \
+    hipLaunchKernelGGL((reduce_sym_kernel<TT, DD>), dim3(grid), dim3(NB_BLOCK), 0, st, rowslab, (const TT *)colslab, \
+                       row_slot0, row_nslots, row_ord, tile_b, n, np, scale, (TT *)acc, (TT *)vel, (TT)half_dt, do_kick)
+    if (dim != 2 && dim != 3) return hipErrorInvalidValue;
+    if (is_f64) { if (dim == 2) NB_RED(double, 2); else NB_RED(double, 3); }
+    else        { if (dim == 2) NB_RED(float, 2); else NB_RED(float, 3); }
+#undef NB_RED
     return hipGetLastError();
 }

@@ -47,13 +47,20 @@ struct SymWork {
     int row_ord;   // ordinal of row tile_i among the rows this rank owns (column-slab index)
 };
 
-hipError_t nb_launch_pack_f64(const double *pos, const double *mass, double *packed, int n, int np, int dim,
-                              double G, hipStream_t st);
+// pack positions + mass factors into padded component arrays; kick != 0 fuses the opening
+// kick + drift of a step (simulation.py:132,135)
+hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mass, void *packed, int n, int np,
+                          int dim, int is_f64, int kick, double half_dt, double dt, double gfac, hipStream_t st);
 hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, int nwork, double *rowslab,
-                                   double *colslab, int np, int dim, int r, double eps2, hipStream_t st);
-hipError_t nb_launch_reduce_sym_f64(const double *rowslab, const double *colslab, const int *row_slot0,
-                                    const int *row_nslots, const int *row_ord, int tile_b, int n, int np, int dim,
-                                    double *acc, double *vel, double half_dt, int do_kick, hipStream_t st);
+                                   double *colslab, int np, int dim, int r, int uniform, double eps2,
+                                   hipStream_t st);
+hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int nwork, double *rowslab,
+                                   float *colslab, int np, int dim, int r, int uniform, int hook, float eps2,
+                                   const GridTables *tab, float G, hipStream_t st);
+hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
+                                const int *row_nslots, const int *row_ord, int tile_b, int n, int np, int dim,
+                                int is_f64, double scale, void *acc, void *vel, double half_dt, int do_kick,
+                                hipStream_t st);
 
 // ---- kernel launchers (implemented in the .hip files) --------------------------------------
 // T = storage/accumulation type of the state (float or double); pa_f32 != 0 selects fp32

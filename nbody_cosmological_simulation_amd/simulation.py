@@ -276,16 +276,8 @@ class GalaxySimulation:
         return ms.value, n.value
 
     def force_kernel_name(self) -> str:
-        """Name of the kernel nb_step uses for the force sum in the current state (for profiles)."""
-        import os
-        dts = (C.c_int32 * 4)()
-        N.check(N.lib().nb_state_dtypes(self._handle, dts))
-        if self.precision_mode != PrecisionMode.FLOAT64:
-            return "force_f32_kernel"
-        sym_default = "1" if self.num_stars >= 4096 else "0"
-        if os.environ.get("NB_SYM", sym_default) == "1" and dts[0] == N.NB_F64:
-            return "force_sym_f64_kernel"
-        return "force_f64_kernel"
+        """Kernel the last force evaluation launched (matches the rocprofv3 kernel-trace rows)."""
+        return N.lib().nb_force_kernel_name(self._handle).decode()
 
     def quant_debug(self, bins: bool = False):
         """Grid internals of the last force evaluation (INT8/INT4/CUSTOM modes)."""

@@ -421,9 +421,10 @@ print("RCCL-1RANK-OK")
     assert "RCCL-1RANK-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
 
 
+@pytest.mark.parametrize("uniform", [False, True])
 @pytest.mark.parametrize("r", [1, 2, 4])
 @pytest.mark.parametrize("n,d", [(65, 2), (257, 3), (1000, 2), (4099, 2), (6000, 3)])
-def test_pair_symmetric_kernel_vs_oracle(nb, monkeypatch, n, d, r):
+def test_pair_symmetric_kernel_vs_oracle(nb, monkeypatch, n, d, r, uniform):
     """The pair-symmetric fp64 kernel (nb_force_sym.hip) forced on for ragged / small sizes."""
     from oracle import oracle as O
     if r == 4 and d == 3:
@@ -433,8 +434,9 @@ def test_pair_symmetric_kernel_vs_oracle(nb, monkeypatch, n, d, r):
     rng = np.random.default_rng(n + d + r)
     pos = rng.standard_normal((n, d)) * 5
     vel = rng.standard_normal((n, d)) * 0.05
-    mass = 0.5 + rng.random(n)
+    mass = np.full(n, 0.7) if uniform else 0.5 + rng.random(n)    # uniform masses take the 14-op kernel
     sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode.FLOAT64)
+    assert sim.force_kernel_name() == "force_sym_f64_kernel"
     assert relerr(sim.accelerations.numpy(), O.accelerations_f64_fast(pos, mass)) < 1e-13
     ref = O.OracleSim(pos, vel, mass, "float64")
     sim.run(3)
@@ -445,3 +447,53 @@ def test_pair_symmetric_kernel_vs_oracle(nb, monkeypatch, n, d, r):
     sim2 = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode.FLOAT64)
     sim2.run(3)
     assert np.array_equal(sim.positions.numpy(), sim2.positions.numpy())
+
+
+@pytest.mark.parametrize("uniform", [False, True])
+@pytest.mark.parametrize("mode", ["float32", "bfloat16", "float16", "int8_sim", "int4_sim", "custom"])
+@pytest.mark.parametrize("n,d,r", [(300, 2, 2), (1000, 2, 4), (777, 3, 2), (4099, 2, 4)])
+def test_pair_symmetric_fp32_kernels_vs_oracle(nb, monkeypatch, n, d, r, mode, uniform):
+    """fp32-state pair-symmetric kernels (all hooks) forced on for ragged / small sizes."""
+    from oracle import oracle as O
+    monkeypatch.setenv("NB_SYM", "1")
+    monkeypatch.setenv("NB_SYM_R", str(r))
+    rng = np.random.default_rng(n + d)
+    pos = (rng.standard_normal((n, d)) * 5).astype(np.float32)
+    vel = (rng.standard_normal((n, d)) * 0.05).astype(np.float32)
+    mass = (np.full(n, 0.7) if uniform else 0.5 + rng.random(n)).astype(np.float32)
+    sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode(mode))
+    assert sim.force_kernel_name() == "force_sym_f32_kernel"
+    ref, dbg = O.accelerations(pos, mass, mode, debug=True)
+    acc = sim.accelerations.numpy()
+    assert acc.dtype == np.float32
+    if mode in GRID:
+        got = sim.quant_debug(bins=True)
+        assert np.array_equal(got["d2bins"], dbg["d2bins"])
+    if mode in ("int8_sim", "int4_sim"):
+        flips = int((got["fbins"] != dbg["fbins"]).sum())
+        assert flips <= 2
+        assert relerr(acc, ref) < (2e-6 if flips == 0 else 2e-2)
+    else:
+        assert relerr(acc, ref) < 2e-6
+    sim.run(2)          # fused kick+drift+pack path
+    o = O.OracleSim(pos, vel, mass, mode)
+    o.run(2)
+    tol = 5e-6 if mode not in ("int8_sim", "int4_sim") else 5e-3
+    assert relerr(sim.positions.numpy(), o.positions) < tol
+
+
+def test_fp16_hook_overflow_gives_zero_force(nb):
+    """quantization.py:56: r2 beyond the fp16 range becomes inf -> pow(inf,1.5)=inf -> G/inf = 0."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    pos = (rng.standard_normal((600, 2)) * 300).astype(np.float32)      # most r2 > 65504
+    mass = np.ones(600, np.float32)
+    for sym in ("0", "1"):
+        os.environ["NB_SYM"] = sym
+        try:
+            sim = nb.GalaxySimulation(T(pos), torch.zeros(600, 2), T(mass), precision_mode=nb.PrecisionMode.FLOAT16)
+        finally:
+            del os.environ["NB_SYM"]
+        acc = sim.accelerations.numpy()
+        assert np.isfinite(acc).all()
+        assert relerr(acc, O.accelerations(pos, mass, "float16")) < 2e-6
