@@ -301,6 +301,9 @@ r2max_kernel(const float *__restrict__ pos, ForceGeom g, float eps2, GridTables 
 
     unsigned int best = 0;
     for (int jt = j_lo; jt < j_hi; jt += NB_TJ) {
+        // r2 is symmetric: source tiles entirely below this block's targets are covered by the
+        // mirrored pairs of another block (block-uniform test, so the barriers stay matched)
+        if (jt + NB_TJ <= ibase) continue;
         {
             int j = jt + tid;
             j = j < j_hi ? j : j_hi - 1;
@@ -393,6 +396,16 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
         tab->thr[k] = thr;
     }
     if (k == 0) {
+        // sentinel above the last bin: NaN compares false, so a lookup can never step past L-1
+        tab->thr[levels] = __builtin_nanf("");
+        // fast bin estimate for the pair loop: n ~ log2(r2) * a + b with a = ln2*(L-1)/range.
+        // v_log_f32 is good to ~1e-6 absolute, so for a < 1e4 the estimate is within 0.01 bins of the
+        // exact (monotone) formula and rint() of it is off by at most one bin, which two threshold
+        // compares repair exactly.  Narrow grids (a >= 1e4) keep the binary search.
+        const double a = 0.6931471805599453 * (double)lm1 / (double)range;
+        tab->est_a = (float)a;
+        tab->est_b = (float)(-(double)lmin * (double)lm1 / (double)range);
+        tab->use_est = (range >= 1e-10f && a < 1.0e4) ? 1 : 0;
         tab->lmin = lmin;
         tab->lmax = lmax;
         tab->range = range;

@@ -76,15 +76,32 @@ __device__ __forceinline__ int grid_bin_lookup(const float *thr, float r2)
     return k;
 }
 
+// Exact bin from an estimate: k0 = rint(log2(r2)*a + b) is within one bin of the true index
+// (grid_tables_kernel guarantees it when tab->use_est), thr[k0] / thr[k0+1] settle it.
+__device__ __forceinline__ int grid_bin_estimate(const float *thr, float r2, float est_a, float est_b, int lmax_bin)
+{
+    const float ne = __builtin_fmaf(__builtin_amdgcn_logf(r2), est_a, est_b);
+    int k0 = (int)(ne + 0.5f);
+    k0 = min(max(k0, 0), lmax_bin);
+    const float lo = thr[k0], hi = thr[k0 + 1];
+    return k0 - ((r2 < lo) ? 1 : 0) + ((r2 >= hi) ? 1 : 0);
+}
+
 // One tile-vs-tile sweep: 64 steps, R*R pairs per lane per step, J data rotating by one lane.
 // DIAG:    J is the target tile itself -> one-sided (each ordered pair once, mirrors dropped).
 // UNIFORM: all masses equal -> the mass factor is applied once to the finished sums
 //          (reduce_sym_kernel), saving both mass multiplies and the rotation of the masses.
 // HOOK:    precision hook applied to the fp32 r2 (HOOK_NONE for fp64).
-template <typename T, int D, int R, bool DIAG, bool UNIFORM, int HOOK>
+struct GridArgs {
+    const float *thr, *lut;
+    float est_a, est_b, gfac;
+    int lmax_bin;
+    bool degenerate;
+};
+
+template <typename T, int D, int R, bool DIAG, bool UNIFORM, int HOOK, bool EST>
 __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (&ai)[R][D], T (&xj)[R][D],
-                                      T (&gj)[R], T (&aj)[R][D], T eps2, int rot_addr, const float *s_thr,
-                                      const float *s_lut, bool degenerate, float gfac)
+                                      T (&gj)[R], T (&aj)[R][D], T eps2, int rot_addr, const GridArgs &ga)
 {
     T c15 = (T)1.5, c1875 = (T)1.875;
     if constexpr (std::is_same_v<T, double>) asm volatile("" : "+v"(c15), "+s"(c1875));
@@ -111,10 +128,12 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
                     if (D == 3) r2 = __fadd_rn(r2, __fmul_rn(d[2], d[2]));
                     r2 = __fadd_rn(r2, eps2);
                     if (HOOK == HOOK_GRID) {
-                        if (!degenerate) {
-                            w = s_lut[grid_bin_lookup<NB_MAX_LUT>(s_thr, r2)];   // (1/q^1.5)*G
+                        if (ga.degenerate) {
+                            w = inv_r3_sym((r2 < 0.01f) ? 0.01f : r2, c15, c1875) * ga.gfac;
+                        } else if (EST) {
+                            w = ga.lut[grid_bin_estimate(ga.thr, r2, ga.est_a, ga.est_b, ga.lmax_bin)];
                         } else {
-                            w = inv_r3_sym((r2 < 0.01f) ? 0.01f : r2, c15, c1875) * gfac;
+                            w = ga.lut[grid_bin_lookup<NB_MAX_LUT>(ga.thr, r2)];   // (1/q^1.5)*G
                         }
                     } else {
                         float q = r2;
@@ -165,19 +184,26 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
     constexpr int B = 64 * R;
     constexpr bool F32 = std::is_same_v<T, float>;
     __shared__ double s_ai[NB_BLOCK / 64][R][D][64];
-    __shared__ float s_thr[HOOK == HOOK_GRID ? NB_MAX_LUT : 1];
+    __shared__ float s_thr[HOOK == HOOK_GRID ? NB_MAX_LUT + 1 : 1];
     __shared__ float s_lut[HOOK == HOOK_GRID ? NB_MAX_LUT : 1];
 
     const SymWork wk = work[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rot_addr = ((lane + 1) & 63) << 2;
-    bool degenerate = false;
+    GridArgs ga{s_thr, s_lut, 0.0f, 0.0f, gfac, 0, false};
+    bool use_est = false;
     if (HOOK == HOOK_GRID) {
-        for (int k = threadIdx.x; k < NB_MAX_LUT; k += NB_BLOCK) {
-            s_thr[k] = (k < tab->levels) ? tab->thr[k] : __builtin_inff();
-            s_lut[k] = (k < tab->levels) ? tab->lut[k] : 0.0f;
+        const int levels = tab->levels;
+        for (int k = threadIdx.x; k <= NB_MAX_LUT; k += NB_BLOCK) {
+            // binary search pads with +inf; the estimate path needs the NaN sentinel at thr[levels]
+            s_thr[k] = (k <= levels) ? tab->thr[k] : __builtin_inff();
+            if (k < NB_MAX_LUT) s_lut[k] = (k < levels) ? tab->lut[k] : 0.0f;
         }
-        degenerate = tab->degenerate != 0;
+        ga.degenerate = tab->degenerate != 0;
+        ga.est_a = tab->est_a;
+        ga.est_b = tab->est_b;
+        ga.lmax_bin = levels - 1;
+        use_est = tab->use_est != 0;
         __syncthreads();
     }
 
@@ -207,10 +233,15 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
             }
             gj[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
         }
-        if (J == wk.tile_i) {                   // wave-uniform
-            sweep<T, D, R, true, UNIFORM, HOOK>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, s_thr, s_lut, degenerate, gfac);
+        const bool diag = (J == wk.tile_i);     // wave-uniform
+        if (HOOK == HOOK_GRID && use_est) {
+            if (diag) sweep<T, D, R, true, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
+            else sweep<T, D, R, false, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
         } else {
-            sweep<T, D, R, false, UNIFORM, HOOK>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, s_thr, s_lut, degenerate, gfac);
+            if (diag) sweep<T, D, R, true, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
+            else sweep<T, D, R, false, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
+        }
+        if (!diag) {
             // column contributions of row I to the particles of tile J (accumulators are home again)
 #pragma unroll
             for (int r = 0; r < R; ++r) {

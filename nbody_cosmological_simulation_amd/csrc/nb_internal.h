@@ -16,11 +16,13 @@ enum { HOOK_NONE = 0, HOOK_BF16 = 1, HOOK_F16 = 2, HOOK_GRID = 3 };
 
 // Device-resident grid tables written by grid_tables_kernel, read by the force kernel.
 struct GridTables {
-    float thr[NB_MAX_LUT];   // thr[k] = smallest fp32 r2 whose bin index is >= k (thr[0] = -inf)
+    float thr[NB_MAX_LUT + 1]; // thr[k] = smallest fp32 r2 whose bin index is >= k (thr[0] = -inf, thr[L] = NaN)
     float lut[NB_MAX_LUT];   // lut[k] = (1 / q_k^1.5) * G   in fp32 (simulation.py:97-101)
     float qval[NB_MAX_LUT];  // q_k = quantised distance-squared value of bin k
     float lmin, lmax, range; // log-grid bounds (quantization.py:109-113)
     float r2max;             // max over all pairs of fp32 r2
+    float est_a, est_b;      // bin estimate: rint(log2(r2)*est_a + est_b) is within +-1 of the exact bin
+    int use_est;             // 1: the estimate is safe (est_a small enough for v_log_f32's error)
     float fmin, fmax;        // linear force grid bounds (quantization.py:78-79)
     int degenerate;          // 1: lmax-lmin < 1e-10 -> values pass through clamped
     int fdegenerate;         // 1: fmax-fmin < 1e-10 -> forces pass through
