@@ -165,7 +165,8 @@ int nb_comm_init(nb_sim *s, const void *id, int32_t id_bytes);
  * (events recorded on the handle's own stream).  total_ms / launches = average duration. */
 int nb_kernel_time(nb_sim *s, double *total_ms, int32_t *launches);
 /* Name of the force kernel the last nb_compute_accelerations / nb_step launched (for matching
- * rocprofv3 rows): "force_sym_f64_kernel", "force_f64_kernel", "force_f32_kernel" or "none". */
+ * rocprofv3 rows by prefix): "force_sym_kernel<double", "force_sym_kernel<float", "force_f64_kernel",
+ * "force_f32_kernel" or "none". */
 const char *nb_force_kernel_name(nb_sim *s);
 /* Block until all work queued on the handle's stream has finished. */
 int nb_synchronize(nb_sim *s);

@@ -380,7 +380,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false)
             HIPCHK(nb_launch_force_sym_f64((const double *)sp.packed, sp.work, sp.nwork, sp.rowslab,
                                            (double *)sp.colslab, sp.np, c.dim, sp.r, s->mass_uniform, c.softening_sq,
                                            s->stream));
-            s->last_kernel = "force_sym_f64_kernel";
+            s->last_kernel = "force_sym_kernel<double";
             if (int rc = prof_end(s, slot)) return rc;
         } else {
             if (int rc = prof_begin(s, &slot)) return rc;
@@ -426,7 +426,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false)
             HIPCHK(nb_launch_force_sym_f32((const float *)sp.packed, sp.work, sp.nwork, sp.rowslab,
                                            (float *)sp.colslab, sp.np, c.dim, sp.r, sym_uniform, hook, eps2, s->tab,
                                            (float)c.G, s->stream));
-            s->last_kernel = "force_sym_f32_kernel";
+            s->last_kernel = "force_sym_kernel<float";
             if (int rc = prof_end(s, slot)) return rc;
         } else {
             if (int rc = prof_begin(s, &slot)) return rc;

@@ -436,7 +436,7 @@ def test_pair_symmetric_kernel_vs_oracle(nb, monkeypatch, n, d, r, uniform):
     vel = rng.standard_normal((n, d)) * 0.05
     mass = np.full(n, 0.7) if uniform else 0.5 + rng.random(n)    # uniform masses take the 14-op kernel
     sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode.FLOAT64)
-    assert sim.force_kernel_name() == "force_sym_f64_kernel"
+    assert sim.force_kernel_name() == "force_sym_kernel<double"
     assert relerr(sim.accelerations.numpy(), O.accelerations_f64_fast(pos, mass)) < 1e-13
     ref = O.OracleSim(pos, vel, mass, "float64")
     sim.run(3)
@@ -462,7 +462,7 @@ def test_pair_symmetric_fp32_kernels_vs_oracle(nb, monkeypatch, n, d, r, mode, u
     vel = (rng.standard_normal((n, d)) * 0.05).astype(np.float32)
     mass = (np.full(n, 0.7) if uniform else 0.5 + rng.random(n)).astype(np.float32)
     sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode(mode))
-    assert sim.force_kernel_name() == "force_sym_f32_kernel"
+    assert sim.force_kernel_name() == "force_sym_kernel<float"
     ref, dbg = O.accelerations(pos, mass, mode, debug=True)
     acc = sim.accelerations.numpy()
     assert acc.dtype == np.float32
