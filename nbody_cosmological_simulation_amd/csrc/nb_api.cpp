@@ -48,6 +48,30 @@ inline int promote(int a, int b)
     return NB_F32;
 }
 inline size_t dt_size(int dt) { return dt == NB_F64 ? 8 : (dt == NB_F32 ? 4 : 2); }
+inline bool is_half(int dt) { return dt == NB_F16 || dt == NB_BF16; }
+
+// host-side round-to-nearest-even to float16 / bfloat16 (only for the O(1) scalars of a call:
+// eps2 and the final energy scalings of half-typed state; torch casts double -> half via float)
+double round_small(double x, int mant, int emin, int emax)
+{
+    if (x == 0.0 || std::isnan(x) || std::isinf(x)) return x;
+    int e;
+    (void)std::frexp(std::fabs(x), &e);
+    const int ue = e - 1;
+    const int q = ue < emin ? emin : ue;
+    const double ulp = std::ldexp(1.0, q - mant);
+    double r = std::nearbyint(std::fabs(x) / ulp) * ulp;
+    if (r > std::ldexp(2.0 - std::ldexp(1.0, -mant), emax)) r = INFINITY;
+    return x < 0 ? -r : r;
+}
+double round_dt(int dt, double x)
+{
+    if (dt == NB_F64) return x;
+    const double f = (double)(float)x;
+    if (dt == NB_F16) return round_small(f, 10, -14, 15);
+    if (dt == NB_BF16) return round_small(f, 7, -126, 127);
+    return f;
+}
 
 // ---- RCCL, resolved lazily so single-GPU use never loads it ---------------------------------
 struct Rccl {
@@ -179,6 +203,7 @@ int build_sym_plan(nb_sim *s)
     int want = (c.n >= 4096) ? 1 : 0;
     if (const char *e = getenv("NB_SYM")) want = atoi(e);
     if (!want || (c.flags & NB_FLAG_NO_COMM)) return NB_OK;
+    if (s->is_f64 && c.mode != NB_FLOAT64) return NB_OK;    // fp64 state under a cast mode: one-sided kernel
     sp.r = (c.dim == 2) ? 4 : 2;       // measured on MI355X, N=65536: R=1 3.39 ms, R=2 1.87 ms, R=4 1.47 ms
     if (const char *e = getenv("NB_SYM_R")) {
         const int r = atoi(e);
@@ -366,10 +391,16 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false)
     bool used_sym = false, sym_uniform = false;
 
     if (s->is_f64) {
-        if (c.mode != NB_FLOAT64)
-            return fail(NB_ERR_UNSUPPORTED, "fp64 state with a non-FLOAT64 precision mode is not implemented yet");
-        const int pa_f32 = (s->logical[0] == NB_F32);
-        used_sym = s->sym.enabled && !pa_f32;
+        if (grid_mode(c.mode))
+            return fail(NB_ERR_UNSUPPORTED, "fp64 state with a grid precision mode is not implemented");
+        int qhook = -1;                      // fp64 positions under a cast mode: hook output is fp32
+        if (c.mode == NB_FLOAT32) qhook = HOOK_NONE;
+        else if (c.mode == NB_BFLOAT16) qhook = HOOK_BF16;
+        else if (c.mode == NB_FLOAT16) qhook = HOOK_F16;
+        if (qhook >= 0 && s->logical[0] != NB_F64)
+            return fail(NB_ERR_UNSUPPORTED, "mixed fp32 positions in fp64 storage under a cast mode");
+        const int pa_f32 = (qhook < 0 && s->logical[0] == NB_F32);
+        used_sym = s->sym.enabled && !pa_f32 && qhook < 0;
         sym_uniform = s->mass_uniform;
         if (used_sym) {
             const auto &sp = s->sym;
@@ -385,7 +416,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false)
         } else {
             if (int rc = prof_begin(s, &slot)) return rc;
             HIPCHK(nb_launch_force_f64((const double *)s->pos, (const double *)s->mass, s->partial, s->geom, c.dim,
-                                       pa_f32, c.G, c.softening_sq, s->stream));
+                                       pa_f32, qhook, c.G, c.softening_sq, s->stream));
             s->last_kernel = "force_f64_kernel";
             if (int rc = prof_end(s, slot)) return rc;
         }
@@ -394,7 +425,10 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false)
         if (c.mode == NB_BFLOAT16) hook = HOOK_BF16;
         else if (c.mode == NB_FLOAT16) hook = HOOK_F16;
         else if (grid_mode(c.mode)) hook = HOOK_GRID;
-        const float eps2 = (float)c.softening_sq;
+        const int pa = is_half(s->logical[0]) ? s->logical[0] : NB_F32;   // half-typed positions (first evaluation)
+        const float eps2 = (float)round_dt(pa, c.softening_sq);
+        if (pa != NB_F32 && hook == HOOK_GRID)
+            return fail(NB_ERR_UNSUPPORTED, "grid modes on float16/bfloat16 state are not implemented");
         if (hook == HOOK_GRID) {
             const int L = mode_levels(c);
             if (L > NB_MAX_LUT || L < 2)
@@ -413,7 +447,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false)
                                          s->stream));
             HIPCHK(nb_launch_grid_tables(s->tab, L, (float)c.G, eps2, 0.01f, s->stream));
         }
-        used_sym = s->sym.enabled;
+        used_sym = s->sym.enabled && pa == NB_F32;
         if (used_sym) {
             const auto &sp = s->sym;
             // grid LUT already carries G (simulation.py:101), so the packed factor is the bare mass there
@@ -431,7 +465,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false)
         } else {
             if (int rc = prof_begin(s, &slot)) return rc;
             HIPCHK(nb_launch_force_f32((const float *)s->pos, (const float *)s->mass, s->partial, s->geom, c.dim, hook,
-                                       (float)c.G, eps2, s->tab, s->stream));
+                                       pa, (float)c.G, eps2, s->tab, s->stream));
             s->last_kernel = "force_f32_kernel";
             if (int rc = prof_end(s, slot)) return rc;
         }
@@ -545,12 +579,15 @@ int nb_set_params(nb_sim *s, double G, double softening_sq, double dt)
 int nb_set_state(nb_sim *s, const void *pos, const void *vel, const void *mass, int dtype, int on_device)
 {
     if (!s) return fail(NB_ERR_INVALID, "null handle");
-    if (dtype != NB_F32 && dtype != NB_F64)
-        return fail(NB_ERR_UNSUPPORTED, "state dtype %d: only float32 and float64 state is implemented", dtype);
+    if (dtype < NB_F16 || dtype > NB_F64) return fail(NB_ERR_INVALID, "bad dtype %d", dtype);
     DeviceGuard guard(s->cfg.device);
-    const bool want_f64 = (s->cfg.mode == NB_FLOAT64) || dtype == NB_F64;
-    if (dtype == NB_F64 && s->cfg.mode != NB_FLOAT64)
-        return fail(NB_ERR_UNSUPPORTED, "fp64 state with a non-FLOAT64 precision mode is not implemented yet");
+    const int mode = s->cfg.mode;
+    if (is_half(dtype) && (mode == NB_FLOAT64 || grid_mode(mode)))
+        return fail(NB_ERR_UNSUPPORTED, "float16/bfloat16 state is implemented for the FLOAT32/BFLOAT16/FLOAT16 "
+                                        "precision modes only");
+    if (dtype == NB_F64 && grid_mode(mode))
+        return fail(NB_ERR_UNSUPPORTED, "fp64 state with a grid (INT8/INT4/CUSTOM) precision mode is not implemented");
+    const bool want_f64 = (mode == NB_FLOAT64) || dtype == NB_F64;
     if (int rc = ensure_storage(s, s->have_storage ? s->is_f64 : want_f64)) return rc;
     if (dtype == NB_F64 && !s->is_f64) return fail(NB_ERR_UNSUPPORTED, "cannot upload fp64 data into fp32 state");
     if (pos) { if (int rc = upload(s, pos, dtype, on_device, s->pos, nd(s))) return rc; s->logical[0] = dtype; s->have_pos = true; }
@@ -662,15 +699,19 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential)
     DeviceGuard guard(s->cfg.device);
     const nb_config &c = s->cfg;
     double host[2] = {0, 0};
+    const int hp_v = is_half(s->logical[1]) ? s->logical[1] : -1;   // NB_F16 == 0: "none" is -1
+    const int hp_x = is_half(s->logical[0]) ? s->logical[0] : -1;
     if (kinetic) {
         if (!s->have_vel || !s->have_mass) return fail(NB_ERR_INVALID, "velocities/masses not set");
-        HIPCHK(nb_launch_kinetic(s->vel, s->mass, c.n, c.dim, s->is_f64, s->logical[1] != NB_F64, s->scratch,
+        HIPCHK(nb_launch_kinetic(s->vel, s->mass, c.n, c.dim, s->is_f64, s->logical[1] != NB_F64, hp_v, s->scratch,
                                  s->scalars + 2, s->stream));
     }
     if (potential) {
         if (!s->have_pos || !s->have_mass) return fail(NB_ERR_INVALID, "positions/masses not set");
         HIPCHK(nb_launch_potential(s->pos, s->mass, s->geom, c.dim, s->is_f64, s->logical[0] != NB_F64,
-                                   s->logical[2] != NB_F64, c.softening_sq, s->scratch, s->scalars + 3, s->stream));
+                                   s->logical[2] != NB_F64, hp_x, c.softening_sq,
+                                   (float)round_dt(hp_x >= 0 ? hp_x : NB_F32, c.softening_sq), s->scratch, s->scalars + 3,
+                                   s->stream));
         if ((c.nranks > 1 && !(c.flags & NB_FLAG_NO_COMM)) || s->comm) {
             if (!s->comm) return fail(NB_ERR_COMM, "nranks > 1 but nb_comm_init was not called");
             NCCLCHK(g_rccl.AllReduce(s->scalars + 3, s->scalars + 3, 1, ncclDouble, ncclSum, s->comm, s->stream));
@@ -680,12 +721,12 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential)
     HIPCHK(hipStreamSynchronize(s->stream));
     if (kinetic) {
         // ke = 0.5 * (masses * v_sq).sum() in the promoted dtype of (velocities, masses)
-        if (promote(s->logical[1], s->logical[2]) == NB_F64) *kinetic = 0.5 * host[0];
-        else *kinetic = (double)(0.5f * (float)host[0]);
+        const int t = promote(s->logical[1], s->logical[2]);
+        *kinetic = round_dt(t, round_dt(t, 0.5) * round_dt(t, host[0]));
     }
     if (potential) {
-        if (promote(s->logical[0], s->logical[2]) == NB_F64) *potential = -c.G * host[1];
-        else *potential = (double)((float)(-c.G) * (float)host[1]);
+        const int t = promote(s->logical[0], s->logical[2]);
+        *potential = round_dt(t, round_dt(t, -c.G) * round_dt(t, host[1]));
     }
     return NB_OK;
 }

@@ -79,7 +79,11 @@ __device__ __forceinline__ int grid_bin_lookup(const float *thr, float r2)
 // fp64 state (FLOAT64 mode).  PA_F32: diff and r2 in fp32 (first evaluation on fp32-typed
 // positions), everything after the hook in fp64.
 // ------------------------------------------------------------------------------------------
-template <int D, int R, bool PA_F32>
+// QHOOK != HOOK_NONE: fp64 positions under FLOAT32 / BFLOAT16 / FLOAT16 mode (omega_point_test.py
+// :722-733 builds such sims): diff and r2 in fp64 in the reference's op order, the hook casts r2
+// to fp32 (and through the half type), q^1.5 and G/. stay fp32, the product with the fp64 mass and
+// everything after it is fp64 again (torch promotion).
+template <int D, int R, bool PA_F32, int QHOOK = -1>
 __global__ void __launch_bounds__(NB_BLOCK)
 force_f64_kernel(const double *__restrict__ pos, const double *__restrict__ mass,
                  double *__restrict__ partial, ForceGeom g, double G, double eps2, float eps2_f)
@@ -111,7 +115,7 @@ force_f64_kernel(const double *__restrict__ pos, const double *__restrict__ mass
             j = j < j_hi ? j : j_hi - 1;
 #pragma unroll
             for (int k = 0; k < D; ++k) sj[k][tid] = pos[(size_t)j * D + k];
-            sj[D][tid] = G * mass[j];
+            sj[D][tid] = (QHOOK >= 0) ? mass[j] : G * mass[j];
         }
         __syncthreads();
         const int cnt = min(NB_TJ, j_hi - jt);
@@ -125,6 +129,21 @@ force_f64_kernel(const double *__restrict__ pos, const double *__restrict__ mass
             for (int r = 0; r < R; ++r) {
                 double d[D];
                 double q;
+                if (QHOOK >= 0) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) d[k] = __dsub_rn(xj[k], xi[r][k]);
+                    double s2 = __dadd_rn(__dmul_rn(d[0], d[0]), __dmul_rn(d[1], d[1]));
+                    if (D == 3) s2 = __dadd_rn(s2, __dmul_rn(d[2], d[2]));
+                    float q32 = (float)__dadd_rn(s2, eps2);
+                    if (QHOOK == HOOK_BF16) q32 = round_bf16(q32);
+                    if (QHOOK == HOOK_F16) q32 = round_f16(q32);
+                    float wq = inv_r3_f32(q32) * (float)G;
+                    if (QHOOK == HOOK_F16) wq = (q32 == __builtin_inff()) ? 0.0f : wq;
+                    const double w = __dmul_rn((double)wq, gm);
+#pragma unroll
+                    for (int k = 0; k < D; ++k) acc[r][k] = __builtin_fma(w, d[k], acc[r][k]);
+                    continue;
+                }
                 if (PA_F32) {
                     float df[D];
 #pragma unroll
@@ -162,7 +181,31 @@ force_f64_kernel(const double *__restrict__ pos, const double *__restrict__ mass
 // ------------------------------------------------------------------------------------------
 // fp32 state (FLOAT32 / BFLOAT16 / FLOAT16 / INT8 / INT4 / CUSTOM modes)
 // ------------------------------------------------------------------------------------------
-template <int D, int R, int HOOK, int LP>
+// PA: arithmetic type of diff / r2.  NB_F32 normally; NB_F16 / NB_BF16 for the first evaluation on
+// half-typed state tensors (omega_point_test.py:722-733): every op of simulation.py:83-86 rounds to
+// the half type, the D-term sum accumulates in float and rounds once (torch opmath), eps2 enters
+// as a half scalar.
+template <int PA> __device__ __forceinline__ float round_pa(float x)
+{
+    if (PA == NB_F16) return round_f16(x);
+    if (PA == NB_BF16) return round_bf16(x);
+    return x;
+}
+template <int D, int PA>
+__device__ __forceinline__ float r2_half_state(const float *xi, const float *xj, float eps2_pa, float *d)
+{
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        d[k] = round_pa<PA>(__fsub_rn(xj[k], xi[k]));
+        const float sq = round_pa<PA>(__fmul_rn(d[k], d[k]));
+        s = (k == 0) ? sq : __fadd_rn(s, sq);
+    }
+    s = round_pa<PA>(s);
+    return round_pa<PA>(__fadd_rn(s, eps2_pa));
+}
+
+template <int D, int R, int HOOK, int LP, int PA = NB_F32>
 __global__ void __launch_bounds__(NB_BLOCK)
 force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
                  double *__restrict__ partial, ForceGeom g, float G, float eps2,
@@ -227,9 +270,14 @@ force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float d[D];
+                float r2;
+                if (PA == NB_F32) {
 #pragma unroll
-                for (int k = 0; k < D; ++k) d[k] = __fsub_rn(xj[k], xi[r][k]);
-                const float r2 = r2_f32_exact<D>(d, eps2);
+                    for (int k = 0; k < D; ++k) d[k] = __fsub_rn(xj[k], xi[r][k]);
+                    r2 = r2_f32_exact<D>(d, eps2);
+                } else {
+                    r2 = r2_half_state<D, PA>(xi[r], xj, eps2, d);
+                }
                 float wq;   // (1 / q^1.5) * G   (simulation.py:97-101)
                 if (HOOK == HOOK_GRID) {
                     if (!degenerate) {
@@ -452,53 +500,60 @@ hipError_t dispatch_dim(int dim, F &&f)
 constexpr int R_F32 = 2;
 
 hipError_t nb_launch_force_f64(const double *pos, const double *mass, double *partial, const ForceGeom &g,
-                               int dim, int pa_f32, double G, double eps2_py, hipStream_t st)
+                               int dim, int pa_f32, int qhook, double G, double eps2_py, hipStream_t st)
 {
-    const int r = pa_f32 ? 2 : g.r;   // the fp32-pair first evaluation is compiled for R = 2 only
+    const int r = (pa_f32 || qhook >= 0) ? 2 : g.r;   // the special variants are compiled for R = 2 only
     const dim3 grid((g.n + NB_BLOCK * r - 1) / (NB_BLOCK * r), g.nchunks);
     const float e32 = (float)eps2_py;
-#define NB_F64(DD, RR, PA) \
-    hipLaunchKernelGGL((force_f64_kernel<DD, RR, PA>), grid, dim3(NB_BLOCK), 0, st, pos, mass, partial, g, G, eps2_py, e32)
+#define NB_F64(DD, RR, PA, QH) \
+    hipLaunchKernelGGL((force_f64_kernel<DD, RR, PA, QH>), grid, dim3(NB_BLOCK), 0, st, pos, mass, partial, g, G, eps2_py, e32)
     return dispatch_dim(dim, [&](auto D) {
         constexpr int DD = decltype(D)::value;
-        if (pa_f32) {
-            NB_F64(DD, 2, true);
-        } else if (g.r == 1) NB_F64(DD, 1, false);
-        else if (g.r == 2) NB_F64(DD, 2, false);
-        else NB_F64(DD, 4, false);
+        if (qhook == HOOK_NONE) NB_F64(DD, 2, false, HOOK_NONE);
+        else if (qhook == HOOK_BF16) NB_F64(DD, 2, false, HOOK_BF16);
+        else if (qhook == HOOK_F16) NB_F64(DD, 2, false, HOOK_F16);
+        else if (qhook >= 0) return hipErrorInvalidValue;
+        else if (pa_f32) NB_F64(DD, 2, true, -1);
+        else if (g.r == 1) NB_F64(DD, 1, false, -1);
+        else if (g.r == 2) NB_F64(DD, 2, false, -1);
+        else NB_F64(DD, 4, false, -1);
         return hipGetLastError();
     });
 #undef NB_F64
 }
 
 hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *partial, const ForceGeom &g,
-                               int dim, int hook, float G, float eps2, const GridTables *tab, hipStream_t st)
+                               int dim, int hook, int pa, float G, float eps2, const GridTables *tab, hipStream_t st)
 {
     const dim3 grid((g.n + NB_BLOCK * R_F32 - 1) / (NB_BLOCK * R_F32), g.nchunks);
+#define NB_F32K(DD, HH, LL, PP) \
+    hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HH, LL, PP>), grid, dim3(NB_BLOCK), 0, st, pos, mass, partial, g, G, eps2, tab)
     return dispatch_dim(dim, [&](auto D) {
         constexpr int DD = decltype(D)::value;
+        if (pa != NB_F32) {
+            // half-typed state: cast hooks only (a grid over a half tensor is not implemented)
+            if (hook == HOOK_GRID) return hipErrorInvalidValue;
+            if (pa == NB_F16) {
+                if (hook == HOOK_NONE) NB_F32K(DD, HOOK_NONE, 1, NB_F16);
+                else if (hook == HOOK_BF16) NB_F32K(DD, HOOK_BF16, 1, NB_F16);
+                else NB_F32K(DD, HOOK_F16, 1, NB_F16);
+            } else {
+                if (hook == HOOK_NONE) NB_F32K(DD, HOOK_NONE, 1, NB_BF16);
+                else if (hook == HOOK_BF16) NB_F32K(DD, HOOK_BF16, 1, NB_BF16);
+                else NB_F32K(DD, HOOK_F16, 1, NB_BF16);
+            }
+            return hipGetLastError();
+        }
         switch (hook) {
-        case HOOK_NONE:
-            hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HOOK_NONE, 1>), grid, dim3(NB_BLOCK), 0, st, pos,
-                               mass, partial, g, G, eps2, tab);
-            break;
-        case HOOK_BF16:
-            hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HOOK_BF16, 1>), grid, dim3(NB_BLOCK), 0, st, pos,
-                               mass, partial, g, G, eps2, tab);
-            break;
-        case HOOK_F16:
-            hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HOOK_F16, 1>), grid, dim3(NB_BLOCK), 0, st, pos,
-                               mass, partial, g, G, eps2, tab);
-            break;
-        case HOOK_GRID:
-            hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HOOK_GRID, NB_MAX_LUT>), grid, dim3(NB_BLOCK), 0, st,
-                               pos, mass, partial, g, G, eps2, tab);
-            break;
-        default:
-            return hipErrorInvalidValue;
+        case HOOK_NONE: NB_F32K(DD, HOOK_NONE, 1, NB_F32); break;
+        case HOOK_BF16: NB_F32K(DD, HOOK_BF16, 1, NB_F32); break;
+        case HOOK_F16: NB_F32K(DD, HOOK_F16, 1, NB_F32); break;
+        case HOOK_GRID: NB_F32K(DD, HOOK_GRID, NB_MAX_LUT, NB_F32); break;
+        default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
     });
+#undef NB_F32K
 }
 
 hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float eps2, GridTables *tab,

@@ -68,10 +68,12 @@ hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, cons
 // T = storage/accumulation type of the state (float or double); pa_f32 != 0 selects fp32
 // pair arithmetic for diff / r2 (always for T=float; for T=double it is the FLOAT64-mode first
 // evaluation on fp32-typed positions).
+// qhook >= 0: fp64 positions under a cast mode (hook output fp32); pa: NB_F32, or NB_F16 / NB_BF16 for
+// the first evaluation on half-typed state (eps2 then already rounded to that type).
 hipError_t nb_launch_force_f64(const double *pos, const double *mass, double *partial, const ForceGeom &g,
-                               int dim, int pa_f32, double G, double eps2_py, hipStream_t st);
+                               int dim, int pa_f32, int qhook, double G, double eps2_py, hipStream_t st);
 hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *partial, const ForceGeom &g,
-                               int dim, int hook, float G, float eps2, const GridTables *tab,
+                               int dim, int hook, int pa, float G, float eps2, const GridTables *tab,
                                hipStream_t st);
 hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float eps2, GridTables *tab,
                            hipStream_t st);
@@ -93,10 +95,10 @@ hipError_t nb_launch_force_quant_bins(const float *in, float *out, int64_t count
                                       int16_t *bins, hipStream_t st);
 
 hipError_t nb_launch_kinetic(const void *vel, const void *mass, int n, int dim, int is_f64, int vel_f32_logical,
-                             double *scratch, double *out, hipStream_t st);
+                             int half_pa, double *scratch, double *out, hipStream_t st);
 hipError_t nb_launch_potential(const void *pos, const void *mass, const ForceGeom &g, int dim, int is_f64,
-                               int pa_f32, int mass_f32, double eps2_py, double *scratch, double *out,
-                               hipStream_t st);
+                               int pa_f32, int mass_f32, int half_pa, double eps2_py, float eps2_half,
+                               double *scratch, double *out, hipStream_t st);
 
 // tensor-level hooks (quantization.py module functions)
 hipError_t nb_launch_cast_hook(const void *in, int in_dt, void *out, int mode, int64_t count, hipStream_t st);

@@ -223,6 +223,15 @@ cast_hook_kernel(const TI *__restrict__ in, TO *__restrict__ out, int64_t count)
 }
 
 // ---- energies ----------------------------------------------------------------------------------
+// HP: state tensors typed float16 / bfloat16 (values stored as fp32): every op rounds to that type;
+// HP = -1: no extra rounding (note NB_F16 == 0, so "none" must not be 0)
+template <int HP> __device__ __forceinline__ float round_hp(float x)
+{
+    if (HP == NB_F16) return (float)(_Float16)x;
+    if (HP == NB_BF16) return (float)(__bf16)x;
+    return x;
+}
+
 template <typename T>
 __device__ __forceinline__ double block_sum(double v, double *s_red)
 {
@@ -237,7 +246,7 @@ __device__ __forceinline__ double block_sum(double v, double *s_red)
 }
 
 // 0.5 * sum m * |v|^2 (simulation.py:170-174).  VF32: velocities hold fp32-typed values.
-template <typename T, bool VF32>
+template <typename T, bool VF32, int HP = -1>
 __global__ void __launch_bounds__(NB_BLOCK)
 kinetic_kernel(const T *__restrict__ vel, const T *__restrict__ mass, int n, int dim, double *__restrict__ part)
 {
@@ -248,10 +257,11 @@ kinetic_kernel(const T *__restrict__ vel, const T *__restrict__ mass, int n, int
             float v2 = 0.0f;
             for (int k = 0; k < dim; ++k) {
                 const float v = (float)vel[(size_t)i * dim + k];
-                const float sq = __fmul_rn(v, v);
+                const float sq = round_hp<HP>(__fmul_rn(v, v));
                 v2 = (k == 0) ? sq : __fadd_rn(v2, sq);
             }
-            s += (double)__fmul_rn((float)mass[i], v2);
+            v2 = round_hp<HP>(v2);
+            s += (double)round_hp<HP>(__fmul_rn((float)mass[i], v2));
         } else {
             double v2 = 0.0;
             for (int k = 0; k < dim; ++k) {
@@ -276,7 +286,7 @@ final_sum_kernel(const double *__restrict__ part, int count, double *__restrict_
 }
 
 // sum_{i<j} m_i m_j / sqrt(r2 + eps2) over this rank's sources (simulation.py:176-192)
-template <typename T, int D, bool PA_F32>
+template <typename T, int D, bool PA_F32, int HP = -1>
 __global__ void __launch_bounds__(NB_BLOCK)
 potential_kernel(const T *__restrict__ pos, const T *__restrict__ mass, ForceGeom g, double eps2, float eps2_f,
                  int mass_f32, double *__restrict__ part)
@@ -314,12 +324,13 @@ potential_kernel(const T *__restrict__ pos, const T *__restrict__ mass, ForceGeo
                 float d2 = 0.0f;
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    const float df = __fsub_rn((float)sj[k][jj], (float)xi[k]);
-                    const float sq = __fmul_rn(df, df);
+                    const float df = round_hp<HP>(__fsub_rn((float)sj[k][jj], (float)xi[k]));
+                    const float sq = round_hp<HP>(__fmul_rn(df, df));
                     d2 = (k == 0) ? sq : __fadd_rn(d2, sq);
                 }
-                const float dist = __fsqrt_rn(__fadd_rn(d2, eps2_f));
-                term = (double)__fdiv_rn(__fmul_rn((float)mi, (float)sj[D][jj]), dist);
+                d2 = round_hp<HP>(d2);
+                const float dist = round_hp<HP>(__fsqrt_rn(round_hp<HP>(__fadd_rn(d2, eps2_f))));
+                term = (double)round_hp<HP>(__fdiv_rn(round_hp<HP>(__fmul_rn((float)mi, (float)sj[D][jj])), dist));
             } else {
                 double q = eps2;
 #pragma unroll
@@ -481,7 +492,7 @@ hipError_t nb_launch_cast_hook(const void *in, int in_dt, void *out, int mode, i
 }
 
 hipError_t nb_launch_kinetic(const void *vel, const void *mass, int n, int dim, int is_f64, int vel_f32_logical,
-                             double *scratch, double *out, hipStream_t st)
+                             int half_pa, double *scratch, double *out, hipStream_t st)
 {
     int blocks = (n + NB_BLOCK - 1) / NB_BLOCK;
     if (blocks > 1024) blocks = 1024;
@@ -490,6 +501,10 @@ hipError_t nb_launch_kinetic(const void *vel, const void *mass, int n, int dim, 
             hipLaunchKernelGGL((kinetic_kernel<double, true>), dim3(blocks), dim3(NB_BLOCK), 0, st, (const double *)vel, (const double *)mass, n, dim, scratch);
         else
             hipLaunchKernelGGL((kinetic_kernel<double, false>), dim3(blocks), dim3(NB_BLOCK), 0, st, (const double *)vel, (const double *)mass, n, dim, scratch);
+    } else if (half_pa == NB_F16) {
+        hipLaunchKernelGGL((kinetic_kernel<float, true, NB_F16>), dim3(blocks), dim3(NB_BLOCK), 0, st, (const float *)vel, (const float *)mass, n, dim, scratch);
+    } else if (half_pa == NB_BF16) {
+        hipLaunchKernelGGL((kinetic_kernel<float, true, NB_BF16>), dim3(blocks), dim3(NB_BLOCK), 0, st, (const float *)vel, (const float *)mass, n, dim, scratch);
     } else {
         hipLaunchKernelGGL((kinetic_kernel<float, true>), dim3(blocks), dim3(NB_BLOCK), 0, st, (const float *)vel, (const float *)mass, n, dim, scratch);
     }
@@ -498,17 +513,23 @@ hipError_t nb_launch_kinetic(const void *vel, const void *mass, int n, int dim, 
 }
 
 hipError_t nb_launch_potential(const void *pos, const void *mass, const ForceGeom &g, int dim, int is_f64,
-                               int pa_f32, int mass_f32, double eps2_py, double *scratch, double *out,
-                               hipStream_t st)
+                               int pa_f32, int mass_f32, int half_pa, double eps2_py, float eps2_half,
+                               double *scratch, double *out, hipStream_t st)
 {
     const dim3 grid((g.n + NB_BLOCK - 1) / NB_BLOCK, g.nchunks);
-    const float e32 = (float)eps2_py;
+    const float e32 = (half_pa >= 0) ? eps2_half : (float)eps2_py;
 #define NB_PE(T, D, PA) \
     hipLaunchKernelGGL((potential_kernel<T, D, PA>), grid, dim3(NB_BLOCK), 0, st, (const T *)pos, (const T *)mass, g, eps2_py, e32, mass_f32, scratch)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64) {
         if (pa_f32) { if (dim == 2) NB_PE(double, 2, true); else NB_PE(double, 3, true); }
         else        { if (dim == 2) NB_PE(double, 2, false); else NB_PE(double, 3, false); }
+    } else if (half_pa == NB_F16) {
+        if (dim == 2) hipLaunchKernelGGL((potential_kernel<float, 2, true, NB_F16>), grid, dim3(NB_BLOCK), 0, st, (const float *)pos, (const float *)mass, g, eps2_py, e32, mass_f32, scratch);
+        else hipLaunchKernelGGL((potential_kernel<float, 3, true, NB_F16>), grid, dim3(NB_BLOCK), 0, st, (const float *)pos, (const float *)mass, g, eps2_py, e32, mass_f32, scratch);
+    } else if (half_pa == NB_BF16) {
+        if (dim == 2) hipLaunchKernelGGL((potential_kernel<float, 2, true, NB_BF16>), grid, dim3(NB_BLOCK), 0, st, (const float *)pos, (const float *)mass, g, eps2_py, e32, mass_f32, scratch);
+        else hipLaunchKernelGGL((potential_kernel<float, 3, true, NB_BF16>), grid, dim3(NB_BLOCK), 0, st, (const float *)pos, (const float *)mass, g, eps2_py, e32, mass_f32, scratch);
     } else {
         if (dim == 2) NB_PE(float, 2, true); else NB_PE(float, 3, true);
     }

@@ -497,3 +497,41 @@ def test_fp16_hook_overflow_gives_zero_force(nb):
         acc = sim.accelerations.numpy()
         assert np.isfinite(acc).all()
         assert relerr(acc, O.accelerations(pos, mass, "float16")) < 2e-6
+
+
+@pytest.mark.parametrize("mode", ["float32", "bfloat16", "float16"])
+def test_fp64_state_under_cast_modes(nb, mode):
+    """fp64 tensors with a non-FLOAT64 mode (omega_point_test.py:722-733 'native precision' sims)."""
+    api = json.load(open(os.path.join(GOLDEN, "api.json")))
+    g = load_golden("g4_api.npz")
+    sim = nb.GalaxySimulation(T(g["pos"]).double(), T(g["vel"]).double(), T(g["mass"]).double(),
+                              precision_mode=nb.PrecisionMode(mode), G=0.001, dt=0.01, softening=0.1)
+    r0 = [str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.accelerations.dtype)]
+    assert relerr(sim.accelerations.numpy(), g[f"in64/{mode}/acc0"]) < 2e-6
+    sim.run(3)
+    r1 = [str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.accelerations.dtype)]
+    assert [r0, r1] == api["dtype_timeline_fp64_inputs"][mode]
+    assert relerr(sim.positions.numpy(), g[f"in64/{mode}/pos3"]) < 1e-6
+    ke, pe = g[f"in64/{mode}/e3"]
+    assert abs(sim.get_kinetic_energy() - ke) <= 1e-5 * abs(ke)
+    assert abs(sim.get_potential_energy() - pe) <= 1e-6 * abs(pe)
+
+
+@pytest.mark.parametrize("name", ["float16", "bfloat16"])
+def test_half_precision_state_tensors(nb, name):
+    """f16 / bf16 state in FLOAT32 mode (omega_point_test.py PRECISION_LEVELS)."""
+    api = json.load(open(os.path.join(GOLDEN, "api.json")))
+    g = load_golden("g4_api.npz")
+    tdt = getattr(torch, name)
+    sim = nb.GalaxySimulation(T(g["pos"]).to(tdt), T(g["vel"]).to(tdt), T(g["mass"]).to(tdt),
+                              precision_mode=nb.PrecisionMode.FLOAT32, G=0.001, dt=0.01, softening=0.1)
+    r0 = [str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.accelerations.dtype)]
+    assert relerr(sim.accelerations.numpy(), g[f"in_{name}/acc0"]) < 2e-6
+    pe0 = float(g[f"in_{name}/pe0"])
+    assert abs(sim.get_potential_energy() - pe0) <= 4e-3 * abs(pe0)       # a half-typed scalar upstream
+    assert np.isfinite(sim.get_kinetic_energy())
+    sim.run(3)
+    r1 = [str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.accelerations.dtype)]
+    assert [r0, r1] == api["dtype_timeline_half_inputs_float32_mode"][name]
+    assert relerr(sim.positions.numpy(), g[f"in_{name}/pos3"]) < 1e-5
+    assert relerr(sim.velocities.numpy(), g[f"in_{name}/vel3"]) < 1e-4
