@@ -289,6 +289,11 @@ int ensure_storage(nb_sim *s, bool f64)
     if (force_quant_mode(s->cfg)) HIPCHK(hipMalloc((void **)&s->fbins, cnt * sizeof(int16_t)));
     HIPCHK(hipMemsetAsync(s->acc, 0, cnt * el, s->stream));
     if (int rc = build_sym_plan(s)) return rc;
+    if ((size_t)s->sym.nwork > s->scratch_elems) {
+        (void)hipFree(s->scratch);
+        s->scratch_elems = (size_t)s->sym.nwork;
+        HIPCHK(hipMalloc((void **)&s->scratch, s->scratch_elems * sizeof(double)));
+    }
     s->have_storage = true;
     return NB_OK;
 }
@@ -708,10 +713,22 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential)
     }
     if (potential) {
         if (!s->have_pos || !s->have_mass) return fail(NB_ERR_INVALID, "positions/masses not set");
-        HIPCHK(nb_launch_potential(s->pos, s->mass, s->geom, c.dim, s->is_f64, s->logical[0] != NB_F64,
-                                   s->logical[2] != NB_F64, hp_x, c.softening_sq,
-                                   (float)round_dt(hp_x >= 0 ? hp_x : NB_F32, c.softening_sq), s->scratch, s->scalars + 3,
-                                   s->stream));
+        const auto &sp = s->sym;
+        const bool pe_sym = sp.enabled && hp_x < 0 && (sp.r == 2 || sp.r == 4) && (size_t)sp.nwork <= s->scratch_elems &&
+                            !getenv("NB_NO_PE_SYM");
+        if (pe_sym) {
+            // same tile-pair work list as the force kernel; `packed` is scratch between force evaluations
+            HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, s->is_f64, 0, 0.0, 0.0,
+                                  1.0, s->stream));
+            HIPCHK(nb_launch_potential_sym(sp.packed, sp.work, sp.nwork, s->scratch, sp.np, c.dim, sp.r, s->is_f64,
+                                           s->logical[0] != NB_F64, s->logical[2] != NB_F64, c.softening_sq, s->stream));
+            HIPCHK(nb_launch_final_sum(s->scratch, sp.nwork, s->scalars + 3, s->stream));
+        } else {
+            HIPCHK(nb_launch_potential(s->pos, s->mass, s->geom, c.dim, s->is_f64, s->logical[0] != NB_F64,
+                                       s->logical[2] != NB_F64, hp_x, c.softening_sq,
+                                       (float)round_dt(hp_x >= 0 ? hp_x : NB_F32, c.softening_sq), s->scratch,
+                                       s->scalars + 3, s->stream));
+        }
         if ((c.nranks > 1 && !(c.flags & NB_FLAG_NO_COMM)) || s->comm) {
             if (!s->comm) return fail(NB_ERR_COMM, "nranks > 1 but nb_comm_init was not called");
             NCCLCHK(g_rccl.AllReduce(s->scalars + 3, s->scalars + 3, 1, ncclDouble, ncclSum, s->comm, s->stream));

@@ -365,6 +365,104 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
     }
 }
 
+// Potential energy over the same tile-pair work list: sum over unordered pairs of
+// m_a m_b / sqrt(r2 + eps2) (simulation.py:176-192; the caller applies -G).  Off-diagonal tile
+// pairs hold every unordered pair once; a diagonal tile holds each twice plus the self pairs, so
+// those terms carry weight 1/2 and the self pairs are skipped.  F32T: term arithmetic in fp32 with
+// correctly rounded sqrt / divide (fp32-typed state); otherwise fp64 with v_rsq_f64 + a third-order
+// step.  Per-lane fp64 sums, wave shuffle + LDS block sum, one partial per workgroup.
+template <typename T, int D, int R, bool F32T>
+__global__ void __launch_bounds__(NB_BLOCK)
+potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work, double *__restrict__ part,
+                     int np, double eps2, float eps2_f, int mass_f32)
+{
+    constexpr int B = 64 * R;
+    __shared__ double s_red[NB_BLOCK / 64];
+    const SymWork wk = work[blockIdx.x];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rot_addr = ((lane + 1) & 63) << 2;
+
+    T xi[R][D], mi[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int p = wk.tile_i * B + r * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < D; ++k) xi[r][k] = packed[(size_t)k * np + p];
+        mi[r] = packed[(size_t)D * np + p];
+    }
+    double sum = 0.0;
+    for (int J = wk.jt_begin + wave; J < wk.jt_end; J += NB_BLOCK / 64) {
+        T xj[R][D], mj[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = J * B + r * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < D; ++k) xj[r][k] = packed[(size_t)k * np + p];
+            mj[r] = packed[(size_t)D * np + p];
+        }
+        const bool diag = (J == wk.tile_i);
+        double tsum[R];             // independent chains: a single accumulator would serialise the adds
+#pragma unroll
+        for (int r = 0; r < R; ++r) tsum[r] = 0.0;
+#pragma unroll 1
+        for (int s = 0; s < 64; ++s) {
+#pragma unroll
+            for (int ri = 0; ri < R; ++ri) {
+#pragma unroll
+                for (int rj = 0; rj < R; ++rj) {
+                    double term;
+                    if (F32T) {
+                        float d2 = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            const float df = __fsub_rn((float)xj[rj][k], (float)xi[ri][k]);
+                            const float sq = __fmul_rn(df, df);
+                            d2 = (k == 0) ? sq : __fadd_rn(d2, sq);
+                        }
+                        const float dist = __fsqrt_rn(__fadd_rn(d2, eps2_f));
+                        term = (double)__fdiv_rn(__fmul_rn((float)mi[ri], (float)mj[rj]), dist);
+                    } else {
+                        double q = eps2;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            const double df = (double)xj[rj][k] - (double)xi[ri][k];
+                            q = __builtin_fma(df, df, q);
+                        }
+                        const double y0 = __builtin_amdgcn_rsq(q);
+                        const double e = __builtin_fma(-q * y0, y0, 1.0);
+                        const double y = __builtin_fma(y0 * e, __builtin_fma(e, 0.375, 0.5), y0);
+                        const double mp = mass_f32 ? (double)__fmul_rn((float)mi[ri], (float)mj[rj])
+                                                   : (double)mi[ri] * (double)mj[rj];
+                        term = mp * y;
+                    }
+                    if (ri == rj) term = (diag && s == 0) ? 0.0 : term;     // self pair
+                    tsum[rj] += term;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) xj[r][k] = rot1<T>(xj[r][k], rot_addr);
+                mj[r] = rot1<T>(mj[r], rot_addr);
+            }
+        }
+        double tile = tsum[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) tile += tsum[r];
+        sum += diag ? 0.5 * tile : tile;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) s_red[wave] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = s_red[0];
+#pragma unroll
+        for (int w = 1; w < NB_BLOCK / 64; ++w) t += s_red[w];
+        part[blockIdx.x] = t;
+    }
+}
+
 template <typename T, int D, int R, int HOOK>
 hipError_t launch_sym_u(const T *packed, const SymWork *work, int nwork, double *rowslab, T *colslab, int np,
                         int uniform, T eps2, const GridTables *tab, float gfac, hipStream_t st)
@@ -427,6 +525,28 @@ hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int
     if (dim == 3 && r == 2) { NB_SYM32(3, 2) }
 #undef NB_SYM32
     return hipErrorInvalidValue;
+}
+
+hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int nwork, double *part, int np, int dim,
+                                   int r, int is_f64, int f32_terms, int mass_f32, double eps2, hipStream_t st)
+{
+    const float e32 = (float)eps2;
+#define NB_PES(TT, DD, RR, FF) \
+    hipLaunchKernelGGL((potential_sym_kernel<TT, DD, RR, FF>), dim3(nwork), dim3(NB_BLOCK), 0, st, (const TT *)packed, \
+                       work, part, np, eps2, e32, mass_f32)
+    if (is_f64) {
+        if (dim == 2 && r == 4) { if (f32_terms) NB_PES(double, 2, 4, true); else NB_PES(double, 2, 4, false); }
+        else if (dim == 2 && r == 2) { if (f32_terms) NB_PES(double, 2, 2, true); else NB_PES(double, 2, 2, false); }
+        else if (dim == 3 && r == 2) { if (f32_terms) NB_PES(double, 3, 2, true); else NB_PES(double, 3, 2, false); }
+        else return hipErrorInvalidValue;
+    } else {
+        if (dim == 2 && r == 4) NB_PES(float, 2, 4, true);
+        else if (dim == 2 && r == 2) NB_PES(float, 2, 2, true);
+        else if (dim == 3 && r == 2) NB_PES(float, 3, 2, true);
+        else return hipErrorInvalidValue;
+    }
+#undef NB_PES
+    return hipGetLastError();
 }
 
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,

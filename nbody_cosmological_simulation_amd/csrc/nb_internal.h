@@ -59,6 +59,9 @@ hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, in
 hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int nwork, double *rowslab,
                                    float *colslab, int np, int dim, int r, int uniform, int hook, float eps2,
                                    const GridTables *tab, float G, hipStream_t st);
+hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int nwork, double *part, int np, int dim,
+                                   int r, int is_f64, int f32_terms, int mass_f32, double eps2, hipStream_t st);
+hipError_t nb_launch_final_sum(const double *part, int count, double *out, hipStream_t st);
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
                                 const int *row_nslots, const int *row_ord, int tile_b, int n, int np, int dim,
                                 int is_f64, double scale, void *acc, void *vel, double half_dt, int do_kick,

@@ -491,6 +491,12 @@ hipError_t nb_launch_cast_hook(const void *in, int in_dt, void *out, int mode, i
     return hipGetLastError();
 }
 
+hipError_t nb_launch_final_sum(const double *part, int count, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB_BLOCK), 0, st, part, count, out);
+    return hipGetLastError();
+}
+
 hipError_t nb_launch_kinetic(const void *vel, const void *mass, int n, int dim, int is_f64, int vel_f32_logical,
                              int half_pa, double *scratch, double *out, hipStream_t st)
 {

@@ -438,6 +438,8 @@ def test_pair_symmetric_kernel_vs_oracle(nb, monkeypatch, n, d, r, uniform):
     sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode.FLOAT64)
     assert sim.force_kernel_name() == "force_sym_kernel<double"
     assert relerr(sim.accelerations.numpy(), O.accelerations_f64_fast(pos, mass)) < 1e-13
+    pe_ref = O.potential_energy_f64_fast(pos, mass)
+    assert abs(sim.get_potential_energy() - pe_ref) <= 1e-13 * abs(pe_ref)      # pair-symmetric PE kernel
     ref = O.OracleSim(pos, vel, mass, "float64")
     sim.run(3)
     ref.run(3)
@@ -475,6 +477,8 @@ def test_pair_symmetric_fp32_kernels_vs_oracle(nb, monkeypatch, n, d, r, mode, u
         assert relerr(acc, ref) < (2e-6 if flips == 0 else 2e-2)
     else:
         assert relerr(acc, ref) < 2e-6
+    o0 = O.OracleSim(pos, vel, mass, mode)
+    assert abs(sim.get_potential_energy() - o0.get_potential_energy()) <= 2e-6 * abs(o0.get_potential_energy())
     sim.run(2)          # fused kick+drift+pack path
     o = O.OracleSim(pos, vel, mass, mode)
     o.run(2)
