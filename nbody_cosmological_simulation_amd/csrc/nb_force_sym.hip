@@ -107,10 +107,12 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
     if constexpr (std::is_same_v<T, double>) asm volatile("" : "+v"(c15), "+s"(c1875));
 #pragma unroll 1
     for (int s = 0; s < 64; ++s) {
+        // source slot outermost: once all targets have met source rj its data and accumulator are
+        // final for this step, so their rotation is issued at once and overlaps the remaining slots
 #pragma unroll
-        for (int ri = 0; ri < R; ++ri) {
+        for (int rj = 0; rj < R; ++rj) {
 #pragma unroll
-            for (int rj = 0; rj < R; ++rj) {
+            for (int ri = 0; ri < R; ++ri) {
                 T d[D];
                 T w;
                 if constexpr (std::is_same_v<T, double>) {
@@ -159,15 +161,12 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
                     }
                 }
             }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
 #pragma unroll
             for (int k = 0; k < D; ++k) {
-                xj[r][k] = rot1<T>(xj[r][k], rot_addr);
-                if (!DIAG) aj[r][k] = rot1<T>(aj[r][k], rot_addr);
+                xj[rj][k] = rot1<T>(xj[rj][k], rot_addr);
+                if (!DIAG) aj[rj][k] = rot1<T>(aj[rj][k], rot_addr);
             }
-            if (!UNIFORM) gj[r] = rot1<T>(gj[r], rot_addr);
+            if (!UNIFORM) gj[rj] = rot1<T>(gj[rj], rot_addr);
         }
     }
 }
