@@ -239,7 +239,6 @@ int build_sym_plan(nb_sim *s)
         return (a.jt_end - a.jt_begin) > (b.jt_end - b.jt_begin);
     });
     const size_t el = s->is_f64 ? sizeof(double) : sizeof(float);
-    const size_t slab = (size_t)c.dim * sp.np * sizeof(double);
     const size_t col_bytes = (size_t)c.dim * sp.np * el * (size_t)std::max(nrows, 1);
     if (col_bytes > (size_t)48 << 30) return NB_OK;       // fall back to the one-sided kernel
     sp.nwork = (int)work.size();
@@ -251,7 +250,7 @@ int build_sym_plan(nb_sim *s)
     HIPCHK(hipMalloc((void **)&sp.row_nslots, T * sizeof(int)));
     HIPCHK(hipMalloc((void **)&sp.row_ord, T * sizeof(int)));
     HIPCHK(hipMalloc((void **)&sp.packed, (size_t)(c.dim + 1) * sp.np * el));
-    HIPCHK(hipMalloc((void **)&sp.rowslab, slab * (size_t)std::max(slots, 1)));
+    HIPCHK(hipMalloc((void **)&sp.rowslab, (size_t)c.dim * sp.tile_b * sizeof(double) * (size_t)std::max(slots, 1)));
     HIPCHK(hipMalloc((void **)&sp.colslab, col_bytes));
     HIPCHK(hipMemcpy(sp.work, work.data(), work.size() * sizeof(SymWork), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(sp.row_slot0, slot0.data(), T * sizeof(int), hipMemcpyHostToDevice));

@@ -174,7 +174,7 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
 // T = double: FLOAT64 mode on fp64 state.  T = float: every fp32-state mode (HOOK selects it).
 // packed  [D+1][NP] of T : x, y, (z), mass factor (G*m, or m for HOOK_GRID whose LUT carries G);
 //                          padding particles sit far away (see pack_kernel).
-// rowslab [slot][D][NP] fp64, colslab [row][D][NP] of T.
+// rowslab [slot][D][B] fp64 (one target tile per workgroup slot), colslab [row][D][NP] of T.
 template <typename T, int D, int R, bool UNIFORM, int HOOK>
 __global__ void __launch_bounds__(NB_BLOCK)
 force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work, double *__restrict__ rowslab,
@@ -267,8 +267,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
         double v = s_ai[0][r][k][l];
 #pragma unroll
         for (int w = 1; w < NB_BLOCK / 64; ++w) v += s_ai[w][r][k][l];
-        const int p = wk.tile_i * B + r * 64 + l;
-        rowslab[((size_t)wk.slot * D + k) * np + p] = v;
+        rowslab[((size_t)wk.slot * D + k) * B + r * 64 + l] = v;      // compact: one tile per slot
     }
 }
 
@@ -335,9 +334,10 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
     for (int k = 0; k < D; ++k) s[k] = 0.0;
     if (g == 0) {
         const int s0 = row_slot0[J], ns = row_nslots[J];
+        const int off = pc - J * tile_b;
         for (int c = 0; c < ns; ++c)
 #pragma unroll
-            for (int k = 0; k < D; ++k) s[k] += rowslab[((size_t)(s0 + c) * D + k) * np + pc];
+            for (int k = 0; k < D; ++k) s[k] += rowslab[((size_t)(s0 + c) * D + k) * tile_b + off];
     }
 #pragma unroll 4
     for (int I = g; I < J; I += NB_BLOCK / 64) {

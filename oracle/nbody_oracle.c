@@ -509,6 +509,41 @@ void nbo_accelerations_f32_fast(int n, int d, const float *pos, const float *mas
     free(sx);
 }
 
+/* FLOAT32 mode forces for a SUBSET of targets [i0, i1) against all sources: lets the tests check
+ * N = 1 048 576 (BASELINE config 5 size) on a few thousand particles in seconds. */
+NBO_CLONES
+void nbo_accelerations_f32_fast_sub(int n, int d, const float *pos, const float *mass, float G, float eps2,
+                                    int i0, int i1, float *acc_out)
+{
+    float *sx = (float *)malloc(sizeof(float) * (size_t)n * 4);
+    float *sy = sx + n, *sz = sy + n, *sm = sz + n;
+    for (int j = 0; j < n; ++j) {
+        sx[j] = pos[(long)j * d];
+        sy[j] = pos[(long)j * d + 1];
+        sz[j] = (d > 2) ? pos[(long)j * d + 2] : 0.0f;
+        sm[j] = mass[j];
+    }
+    #pragma omp parallel for schedule(static)
+    for (int i = i0; i < i1; ++i) {
+        const float xi = sx[i], yi = sy[i], zi = sz[i];
+        double ax = 0, ay = 0, az = 0;
+        #pragma omp simd reduction(+:ax,ay,az)
+        for (int j = 0; j < n; ++j) {
+            float dx = sx[j] - xi, dy = sy[j] - yi, dz = sz[j] - zi;
+            float r2 = dx * dx + dy * dy;
+            if (d > 2) r2 = r2 + dz * dz;
+            r2 = r2 + eps2;
+            float w = ((1.0f / (r2 * sqrtf(r2))) * G) * sm[j];
+            w = (j == i) ? 0.0f : w;
+            ax += (double)(w * dx); ay += (double)(w * dy); az += (double)(w * dz);
+        }
+        float *o = acc_out + (long)(i - i0) * d;
+        o[0] = (float)ax; o[1] = (float)ay;
+        if (d > 2) o[2] = (float)az;
+    }
+    free(sx);
+}
+
 /* fp64 KDK step on top of the fast force (all-f64 state, FLOAT64 mode) */
 void nbo_step_f64_fast(int n, int d, double *pos, double *vel, const double *mass, double *acc,
                        double G, double eps2, double dt, int nsteps)

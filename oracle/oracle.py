@@ -69,6 +69,9 @@ def lib():
         L.nbo_accelerations_f32_fast.restype = None
         L.nbo_accelerations_f32_fast.argtypes = [C.c_int, C.c_int, fp, fp, C.c_float, C.c_float,
                                                  C.c_int, C.c_int, fp]
+        L.nbo_accelerations_f32_fast_sub.restype = None
+        L.nbo_accelerations_f32_fast_sub.argtypes = [C.c_int, C.c_int, fp, fp, C.c_float, C.c_float,
+                                                     C.c_int, C.c_int, fp]
         L.nbo_step_f64_fast.restype = None
         L.nbo_step_f64_fast.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, C.c_double, C.c_double,
                                         C.c_double, C.c_int]
@@ -194,6 +197,18 @@ def accelerations_f32_fast(pos, mass, G=0.001, softening=0.1, j_range=None):
     lib().nbo_accelerations_f32_fast(n, d, p.ctypes.data_as(fp), m.ctypes.data_as(fp),
                                      np.float32(G), np.float32(float(softening) ** 2), j0, j1,
                                      out.ctypes.data_as(fp))
+    return out
+
+
+def accelerations_f32_fast_subset(pos, mass, i0, i1, G=0.001, softening=0.1):
+    """FLOAT32-mode forces on targets [i0, i1) only (all sources)."""
+    n, d = pos.shape
+    p = np.ascontiguousarray(pos, np.float32)
+    m = np.ascontiguousarray(mass, np.float32)
+    out = np.empty((i1 - i0, d), np.float32)
+    fp = C.POINTER(C.c_float)
+    lib().nbo_accelerations_f32_fast_sub(n, d, p.ctypes.data_as(fp), m.ctypes.data_as(fp), np.float32(G),
+                                         np.float32(float(softening) ** 2), i0, i1, out.ctypes.data_as(fp))
     return out
 
 
