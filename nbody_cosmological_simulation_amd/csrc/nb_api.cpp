@@ -378,7 +378,9 @@ int prof_end(nb_sim *s, int slot)
 }
 
 // one evaluation of simulation.py:74-118; optionally followed by the closing half kick (:141)
-int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false)
+// defer_kick: the caller will apply the closing half kick itself (fused into the next step's
+// opening launch) when this evaluation cannot fuse it into its reduction.
+int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_kick = nullptr)
 {
     if (!s->have_pos || !s->have_mass) return fail(NB_ERR_INVALID, "positions and masses must be set first");
     const nb_config &c = s->cfg;
@@ -495,7 +497,10 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false)
         HIPCHK(nb_launch_force_quant_bins((const float *)s->acc, (float *)s->acc, cnt, mode_levels(c), s->scalars,
                                           s->fbins, s->stream));
     }
-    if (do_kick && !fuse_kick) HIPCHK(nb_launch_axpy(s->vel, s->acc, half_dt, cnt, s->is_f64, s->stream));
+    if (do_kick && !fuse_kick) {
+        if (defer_kick) *defer_kick = true;
+        else HIPCHK(nb_launch_axpy(s->vel, s->acc, half_dt, cnt, s->is_f64, s->stream));
+    }
     s->logical[3] = acc_logical_dtype(s);
     s->have_acc = true;
     return NB_OK;
@@ -678,20 +683,27 @@ int nb_step(nb_sim *s, int32_t nsteps)
     if (!s->have_vel || !s->have_pos || !s->have_mass) return fail(NB_ERR_INVALID, "state incomplete");
     if (!s->have_acc) return fail(NB_ERR_INVALID, "no accelerations yet: call nb_compute_accelerations first");
     DeviceGuard guard(s->cfg.device);
+    bool pending_close = false;     // closing kick of the previous step still to be applied
     for (int t = 0; t < nsteps; ++t) {
         // opening kick + drift; on the pair-symmetric path the repack rides in the same launch
         const int sdt = s->is_f64 ? NB_F64 : NB_F32;
         const bool fuse_pack = s->sym.enabled && s->logical[0] == sdt && s->logical[1] == sdt &&
                                s->logical[3] == sdt && !grid_mode(s->cfg.mode);
-        if (fuse_pack)
+        if (fuse_pack) {
             HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, s->sym.packed, s->cfg.n, s->sym.np, s->cfg.dim,
-                                  s->is_f64, 1, s->cfg.dt / 2, s->cfg.dt, s->is_f64 ? s->cfg.G : (double)(float)s->cfg.G,
-                                  s->stream));
-        else
+                                  s->is_f64, pending_close ? 2 : 1, s->cfg.dt / 2, s->cfg.dt,
+                                  s->is_f64 ? s->cfg.G : (double)(float)s->cfg.G, s->stream));
+        } else {
+            if (pending_close) HIPCHK(nb_launch_axpy(s->vel, s->acc, s->cfg.dt / 2, nd(s), s->is_f64, s->stream));
             HIPCHK(nb_launch_kick_drift(s->pos, s->vel, s->acc, s->cfg.dt / 2, s->cfg.dt, nd(s), s->is_f64, s->stream));
+        }
+        pending_close = false;
         s->logical[1] = promote(s->logical[1], s->logical[3]);
         s->logical[0] = promote(s->logical[0], s->logical[1]);
-        if (int rc = force_eval(s, true, fuse_pack)) return rc;
+        // a closing kick that cannot ride in the reduction (RCCL all-reduce / force quantisation in
+        // between) is folded into the next step's opening launch when there is one
+        const bool may_defer = (t + 1 < nsteps) && fuse_pack;
+        if (int rc = force_eval(s, true, fuse_pack, may_defer ? &pending_close : nullptr)) return rc;
         s->logical[1] = promote(s->logical[1], s->logical[3]);
     }
     return NB_OK;

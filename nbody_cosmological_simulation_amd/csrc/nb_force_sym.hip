@@ -284,7 +284,9 @@ template <> __device__ __forceinline__ float axpy_rn<float>(float a, float b, fl
 
 // x, y, (z), mass factor as padded component arrays; with KICK the opening half of a step rides
 // along: v += a*(dt/2); x += v*dt (simulation.py:132,135, separate mul/add roundings like torch).
-template <typename T, int D, bool KICK>
+// KICK = 2 additionally applies the closing half kick of the PREVIOUS step first (simulation.py:141),
+// which the multi-GPU / force-quantising paths cannot fuse into their reduction.
+template <typename T, int D, int KICK>
 __global__ void __launch_bounds__(NB_BLOCK)
 pack_kernel(T *__restrict__ pos, T *__restrict__ vel, const T *__restrict__ acc, const T *__restrict__ mass,
             T *__restrict__ packed, int n, int np, T half_dt, T dt, T gfac)
@@ -297,7 +299,9 @@ pack_kernel(T *__restrict__ pos, T *__restrict__ vel, const T *__restrict__ acc,
             const size_t idx = (size_t)p * D + k;
             T x = pos[idx];
             if (KICK) {
-                const T v = axpy_rn<T>(vel[idx], acc[idx], half_dt);
+                T v = vel[idx];
+                if (KICK == 2) v = axpy_rn<T>(v, acc[idx], half_dt);
+                v = axpy_rn<T>(v, acc[idx], half_dt);
                 x = axpy_rn<T>(x, v, dt);
                 vel[idx] = v;
                 pos[idx] = x;
@@ -484,14 +488,11 @@ hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mas
 #define NB_PACK(TT, DD, KK) \
     hipLaunchKernelGGL((pack_kernel<TT, DD, KK>), dim3(grid), dim3(NB_BLOCK), 0, st, (TT *)pos, (TT *)vel, \
                        (const TT *)acc, (const TT *)mass, (TT *)packed, n, np, (TT)half_dt, (TT)dt, (TT)gfac)
+#define NB_PACK_K(TT, DD) do { if (kick == 2) NB_PACK(TT, DD, 2); else if (kick == 1) NB_PACK(TT, DD, 1); else NB_PACK(TT, DD, 0); } while (0)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
-    if (is_f64) {
-        if (dim == 2) { if (kick) NB_PACK(double, 2, true); else NB_PACK(double, 2, false); }
-        else          { if (kick) NB_PACK(double, 3, true); else NB_PACK(double, 3, false); }
-    } else {
-        if (dim == 2) { if (kick) NB_PACK(float, 2, true); else NB_PACK(float, 2, false); }
-        else          { if (kick) NB_PACK(float, 3, true); else NB_PACK(float, 3, false); }
-    }
+    if (is_f64) { if (dim == 2) NB_PACK_K(double, 2); else NB_PACK_K(double, 3); }
+    else        { if (dim == 2) NB_PACK_K(float, 2); else NB_PACK_K(float, 3); }
+#undef NB_PACK_K
 #undef NB_PACK
     return hipGetLastError();
 }
