@@ -129,6 +129,8 @@ struct nb_sim {
     size_t scratch_elems = 0;
     double *scalars = nullptr;           // device: [0,1] force min/max, [2] ke, [3] pe
     int16_t *fbins = nullptr;            // n*dim, INT8/INT4 only
+    float *prune_cand = nullptr, *prune_rho = nullptr;   // grid modes: pruned max-r2 search
+    PruneState *prune_state = nullptr;
     bool mass_uniform = false;           // all masses equal (checked on the device at upload)
     double mass_value = 0.0;
     const char *last_kernel = "none";
@@ -286,6 +288,11 @@ int ensure_storage(nb_sim *s, bool f64)
     HIPCHK(hipMalloc((void **)&s->scalars, 8 * sizeof(double)));
     HIPCHK(hipMemsetAsync(s->scalars, 0, 8 * sizeof(double), s->stream));
     if (force_quant_mode(s->cfg)) HIPCHK(hipMalloc((void **)&s->fbins, cnt * sizeof(int16_t)));
+    if (!f64 && grid_mode(s->cfg.mode)) {
+        HIPCHK(hipMalloc((void **)&s->prune_cand, cnt * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&s->prune_rho, (size_t)s->cfg.n * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&s->prune_state, sizeof(PruneState)));
+    }
     HIPCHK(hipMemsetAsync(s->acc, 0, cnt * el, s->stream));
     if (int rc = build_sym_plan(s)) return rc;
     if ((size_t)s->sym.nwork > s->scratch_elems) {
@@ -441,16 +448,22 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
                 return fail(NB_ERR_UNSUPPORTED, "grid levels must be in [2, %d] on the fused path (got %d)",
                             NB_MAX_LUT, L);
             HIPCHK(hipMemsetAsync(&s->tab->r2max_bits, 0, sizeof(unsigned int), s->stream));
-            ForceGeom gmax = s->geom;
-            if (no_comm && c.nranks > 1) {   // a comm-less shard scans every source itself
-                gmax.j_begin = 0;
-                gmax.j_end = c.n;
-                gmax.nchunks = (c.n + gmax.chunk_len - 1) / gmax.chunk_len;
+            if (!getenv("NB_NO_PRUNE")) {
+                // every rank finds the global maximum itself: O(N) + (outer candidates)^2, no collective
+                HIPCHK(nb_launch_r2max_pruned((const float *)s->pos, c.n, c.dim, eps2, s->prune_cand, s->prune_rho,
+                                              s->prune_state, s->tab, s->stream));
+            } else {
+                ForceGeom gmax = s->geom;
+                if (no_comm && c.nranks > 1) {   // a comm-less shard scans every source itself
+                    gmax.j_begin = 0;
+                    gmax.j_end = c.n;
+                    gmax.nchunks = (c.n + gmax.chunk_len - 1) / gmax.chunk_len;
+                }
+                HIPCHK(nb_launch_r2max((const float *)s->pos, gmax, c.dim, eps2, s->tab, s->stream));
+                if (multi)   // NB_FLAG_NO_COMM shards see only their own block's maximum
+                    NCCLCHK(g_rccl.AllReduce(&s->tab->r2max_bits, &s->tab->r2max_bits, 1, ncclUint32, ncclMax, s->comm,
+                                             s->stream));
             }
-            HIPCHK(nb_launch_r2max((const float *)s->pos, gmax, c.dim, eps2, s->tab, s->stream));
-            if (multi)   // NB_FLAG_NO_COMM shards see only their own block's maximum
-                NCCLCHK(g_rccl.AllReduce(&s->tab->r2max_bits, &s->tab->r2max_bits, 1, ncclUint32, ncclMax, s->comm,
-                                         s->stream));
             HIPCHK(nb_launch_grid_tables(s->tab, L, (float)c.G, eps2, 0.01f, s->stream));
         }
         used_sym = s->sym.enabled && pa == NB_F32;
@@ -567,7 +580,8 @@ int nb_destroy(nb_sim *s)
     for (void *p : {s->pos, s->vel, s->mass, s->acc, (void *)s->partial, s->staging, (void *)s->tab,
                     (void *)s->scratch, (void *)s->scalars, (void *)s->fbins, (void *)s->sym.work,
                     (void *)s->sym.row_slot0, (void *)s->sym.row_nslots, (void *)s->sym.row_ord,
-                    (void *)s->sym.packed, (void *)s->sym.rowslab, (void *)s->sym.colslab})
+                    (void *)s->sym.packed, (void *)s->sym.rowslab, (void *)s->sym.colslab,
+                    (void *)s->prune_cand, (void *)s->prune_rho, (void *)s->prune_state})
         if (p) (void)hipFree(p);
     if (s->prof_init)
         for (int i = 0; i < PROF_RING; ++i) { (void)hipEventDestroy(s->ev_start[i]); (void)hipEventDestroy(s->ev_stop[i]); }

@@ -386,6 +386,174 @@ r2max_kernel(const float *__restrict__ pos, ForceGeom g, float eps2, GridTables 
 }
 
 // ------------------------------------------------------------------------------------------
+// K2 with pruning.  The pair with the largest r2 lies on the outside of the particle cloud, so a
+// brute-force scan of all N^2 pairs is wasteful.  Exactness argument (all quantities fp32, margins
+// 1e-5 >> the ~4e-7 rounding of r2 and rho):
+//   * c = bounding-box centre, rho_i = |x_i - c|; for any pair dist(a,b) <= rho_a + rho_b <= rho_a + rho_max;
+//   * LB = r2 of a real pair found by two farthest-point hops (far -> g -> h), so max r2 >= LB;
+//   * hence both members of the maximal pair satisfy rho >= sqrt(LB - eps2) - rho_max (up to margins).
+// Candidates passing that test are compacted and scanned exhaustively with the exact r2 formula.
+// For a disk galaxy this keeps a few percent of the particles (~0.1 % of the pairs).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+prune_bbox_kernel(const float *__restrict__ pos, int n, int dim, PruneState *__restrict__ ps)
+{
+    __shared__ float s_mn[3][16], s_mx[3][16];
+    __shared__ int s_nan;
+    if (threadIdx.x == 0) s_nan = 0;
+    __syncthreads();
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    bool bad = false;
+    for (int i = threadIdx.x; i < n; i += 1024)
+        for (int k = 0; k < dim; ++k) {
+            const float v = pos[(size_t)i * dim + k];
+            bad |= (v != v);
+            mn[k] = fminf(mn[k], v);
+            mx[k] = fmaxf(mx[k], v);
+        }
+    if (bad) s_nan = 1;
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { s_mn[k][threadIdx.x >> 6] = mn[k]; s_mx[k][threadIdx.x >> 6] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 3; ++k) {
+            float a = s_mn[k][0], b = s_mx[k][0];
+            for (int w = 1; w < 16; ++w) { a = fminf(a, s_mn[k][w]); b = fmaxf(b, s_mx[k][w]); }
+            ps->center[k] = (k < dim) ? 0.5f * a + 0.5f * b : 0.0f;
+        }
+        ps->far = 0ull;
+        ps->lb[0] = 0ull;
+        ps->lb[1] = 0ull;
+        ps->count = 0;
+        ps->nan_flag = s_nan;
+    }
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+template <int D>
+__global__ void __launch_bounds__(NB_BLOCK)
+prune_rho_kernel(const float *__restrict__ pos, int n, float *__restrict__ rho, PruneState *__restrict__ ps)
+{
+    const int i = blockIdx.x * NB_BLOCK + threadIdx.x;
+    unsigned long long key = 0ull;
+    if (i < n) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const float d = pos[(size_t)i * D + k] - ps->center[k];
+            s += d * d;
+        }
+        const float r = sqrtf(s);
+        rho[i] = r;
+        key = ((unsigned long long)__float_as_uint(r) << 32) | (unsigned int)i;
+    }
+    key = wave_max_u64(key);
+    if ((threadIdx.x & 63) == 0 && key) atomicMax(&ps->far, key);
+}
+
+// farthest partner (by the exact fp32 r2) of the particle whose index is stored in *src_key
+template <int D>
+__global__ void __launch_bounds__(NB_BLOCK)
+prune_hop_kernel(const float *__restrict__ pos, int n, float eps2, const unsigned long long *__restrict__ src_key,
+                 unsigned long long *__restrict__ dst_key)
+{
+    const int f = (int)(*src_key & 0xffffffffull);
+    const int j = blockIdx.x * NB_BLOCK + threadIdx.x;
+    unsigned long long key = 0ull;
+    if (j < n) {
+        float d[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) d[k] = __fsub_rn(pos[(size_t)j * D + k], pos[(size_t)f * D + k]);
+        key = ((unsigned long long)r2_order_bits(r2_f32_exact<D>(d, eps2)) << 32) | (unsigned int)j;
+    }
+    key = wave_max_u64(key);
+    if ((threadIdx.x & 63) == 0 && key) atomicMax(dst_key, key);
+}
+
+template <int D>
+__global__ void __launch_bounds__(NB_BLOCK)
+prune_compact_kernel(const float *__restrict__ pos, const float *__restrict__ rho, int n, float eps2,
+                     float *__restrict__ cand, PruneState *__restrict__ ps)
+{
+    const int i = blockIdx.x * NB_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float lb = __uint_as_float((unsigned int)(ps->lb[1] >> 32));
+    const float rho_max = __uint_as_float((unsigned int)(ps->far >> 32));
+    const float need = sqrtf(fmaxf(lb - eps2, 0.0f)) * (1.0f - 1e-5f) - rho_max * (1.0f + 1e-5f);
+    if (rho[i] * (1.0f + 1e-5f) >= need) {
+        const int slot = atomicAdd(&ps->count, 1);
+#pragma unroll
+        for (int k = 0; k < D; ++k) cand[(size_t)slot * D + k] = pos[(size_t)i * D + k];
+    }
+}
+
+// exhaustive exact max over the compacted candidates (count read on the device)
+template <int D>
+__global__ void __launch_bounds__(NB_BLOCK)
+prune_scan_kernel(const float *__restrict__ cand, float eps2, const PruneState *__restrict__ ps,
+                  GridTables *__restrict__ tab)
+{
+    __shared__ float sj[D][NB_TJ];
+    __shared__ unsigned int s_red[NB_BLOCK / 64];
+    const int m = ps->count;
+    const int tid = threadIdx.x;
+    const int ibase = blockIdx.x * NB_BLOCK;
+    if (ps->nan_flag) {                          // a NaN coordinate: torch's max() would be NaN
+        if (blockIdx.x == 0 && tid == 0) atomicMax(&tab->r2max_bits, 0x7fc00000u);
+        return;
+    }
+    if (ibase >= m) return;                      // block-uniform
+    const int i = min(ibase + tid, m - 1);
+    float xi[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) xi[k] = cand[(size_t)i * D + k];
+    unsigned int best = 0;
+    for (int jt = ibase; jt < m; jt += NB_TJ) {  // r2 is symmetric: tiles below the block are mirrored elsewhere
+        {
+            const int j = min(jt + tid, m - 1);
+#pragma unroll
+            for (int k = 0; k < D; ++k) sj[k][tid] = cand[(size_t)j * D + k];
+        }
+        __syncthreads();
+        const int cnt = min(NB_TJ, m - jt);
+#pragma unroll 8
+        for (int jj = 0; jj < cnt; ++jj) {
+            float d[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) d[k] = __fsub_rn(sj[k][jj], xi[k]);
+            best = max(best, r2_order_bits(r2_f32_exact<D>(d, eps2)));
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = max(best, (unsigned int)__shfl_xor((int)best, off, 64));
+    if ((tid & 63) == 0) s_red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int b = s_red[0];
+#pragma unroll
+        for (int w = 1; w < NB_BLOCK / 64; ++w) b = max(b, s_red[w]);
+        atomicMax(&tab->r2max_bits, b);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Grid tables: exact scalar form of _grid_quantize_safe (quantization.py:91-127) evaluated on
 // the device once per force evaluation.  Every stage (clamp, log, -lmin, /range, *(L-1), round)
 // is monotone in r2, so the bin index is a step function of the fp32 r2: thread k finds the
@@ -564,6 +732,22 @@ hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float 
     return dispatch_dim(dim, [&](auto D) {
         constexpr int DD = decltype(D)::value;
         hipLaunchKernelGGL((r2max_kernel<DD, R>), grid, dim3(NB_BLOCK), 0, st, pos, g, eps2, tab);
+        return hipGetLastError();
+    });
+}
+
+hipError_t nb_launch_r2max_pruned(const float *pos, int n, int dim, float eps2, float *cand, float *rho,
+                                  PruneState *ps, GridTables *tab, hipStream_t st)
+{
+    const int blocks = (n + NB_BLOCK - 1) / NB_BLOCK;
+    hipLaunchKernelGGL(prune_bbox_kernel, dim3(1), dim3(1024), 0, st, pos, n, dim, ps);
+    return dispatch_dim(dim, [&](auto D) {
+        constexpr int DD = decltype(D)::value;
+        hipLaunchKernelGGL((prune_rho_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, pos, n, rho, ps);
+        hipLaunchKernelGGL((prune_hop_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, pos, n, eps2, &ps->far, &ps->lb[0]);
+        hipLaunchKernelGGL((prune_hop_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, pos, n, eps2, &ps->lb[0], &ps->lb[1]);
+        hipLaunchKernelGGL((prune_compact_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, pos, rho, n, eps2, cand, ps);
+        hipLaunchKernelGGL((prune_scan_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, cand, eps2, ps, tab);
         return hipGetLastError();
     });
 }

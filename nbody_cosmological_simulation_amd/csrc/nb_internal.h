@@ -31,6 +31,15 @@ struct GridTables {
     unsigned int fmin_bits, fmax_bits;
 };
 
+// Scratch of the pruned max-r2 search (nb_force.hip "K2 with pruning").
+struct PruneState {
+    float center[3];          // bounding-box centre
+    unsigned long long far;   // (rho bits << 32 | index) of the particle farthest from the centre
+    unsigned long long lb[2]; // (r2 bits << 32 | index): farthest partner of `far`, then of that partner
+    int count;                // candidates kept
+    int nan_flag;             // a NaN coordinate was seen -> r2max is NaN
+};
+
 struct ForceGeom {
     int n;          // particles
     int j_begin;    // first source of this rank's block
@@ -80,6 +89,10 @@ hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *part
                                hipStream_t st);
 hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float eps2, GridTables *tab,
                            hipStream_t st);
+// exact max of the fp32 r2 over all pairs via candidate pruning (every rank computes it redundantly,
+// O(N) + (candidates)^2 work, no collective); cand: n*dim floats, rho: n floats, st: PruneState
+hipError_t nb_launch_r2max_pruned(const float *pos, int n, int dim, float eps2, float *cand, float *rho,
+                                  PruneState *ps, GridTables *tab, hipStream_t st);
 hipError_t nb_launch_grid_tables(GridTables *tab, int levels, float G, float eps2, float min_val,
                                  hipStream_t st);
 hipError_t nb_launch_d2bins(const float *pos, int n, int dim, float eps2, const GridTables *tab,

@@ -612,3 +612,29 @@ def test_baseline_config_4_5_sizes_fp32(nb, n):
                  for r in range(4)]
         s = nb.GalaxySimulation(pos, vel, mass, precision_mode=nb.PrecisionMode.FLOAT32)
         assert relerr(sum(parts), s.accelerations.numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["int8_sim", "int4_sim"])
+def test_grid_modes_pruned_max_r2_edge_cases(nb, mode):
+    """The pruned max-r2 search (exact by construction) on awkward clouds: a far outlier, collinear
+    points, all particles coincident (degenerate grid), and a NaN coordinate (everything NaN upstream)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    clouds = {
+        "outlier": np.vstack([rng.standard_normal((500, 2)) * 2, [[400.0, -300.0]]]).astype(np.float32),
+        "collinear": np.stack([np.linspace(-30, 30, 300), np.zeros(300)], 1).astype(np.float32),
+        "ring": np.stack([10 * np.cos(np.linspace(0, 6.28, 400)), 10 * np.sin(np.linspace(0, 6.28, 400))], 1).astype(np.float32),
+        "coincident": np.zeros((64, 2), np.float32),
+    }
+    for name, pos in clouds.items():
+        n = pos.shape[0]
+        mass = np.ones(n, np.float32)
+        sim = nb.GalaxySimulation(T(pos), torch.zeros(n, 2), T(mass), precision_mode=nb.PrecisionMode(mode))
+        ref, dbg = O.accelerations(pos, mass, mode, debug=True)
+        got = sim.quant_debug(bins=True)
+        assert np.float32(got["lmax"]) == np.float32(dbg["lmax"]), name
+        assert np.array_equal(got["d2bins"], dbg["d2bins"]), name
+    pos = clouds["ring"].copy()
+    pos[7, 1] = np.nan
+    sim = nb.GalaxySimulation(T(pos), torch.zeros(400, 2), torch.ones(400), precision_mode=nb.PrecisionMode(mode))
+    assert torch.isnan(sim.accelerations).all()
