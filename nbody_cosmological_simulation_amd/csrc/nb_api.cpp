@@ -223,7 +223,8 @@ int build_sym_plan(nb_sim *s)
         owner[I] = k < P ? k : 2 * P - 1 - k;
         if (owner[I] == c.rank) { ord[I] = nrows++; owned_pairs += T - I; }
     }
-    int cl = (int)((owned_pairs / 2048 + 3) / 4 * 4);
+    // ~6000 workgroups per launch: measured at N=65536 (R=4) cl = 4/8/16/32/64 -> 1.27/1.26/1.29/1.38/1.52 ms
+    int cl = (int)((owned_pairs / 6144 + 3) / 4 * 4);
     cl = std::max(4, std::min(cl, 64));
     if (const char *e = getenv("NB_SYM_CL")) cl = std::max(4, atoi(e) / 4 * 4);
     std::vector<SymWork> work;
