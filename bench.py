@@ -62,7 +62,23 @@ def cpu_baseline(pos, vel, mass, target_s):
     t0 = time.perf_counter()
     lib.nbo_step_f64_fast(n, d, O._dp(p), O._dp(v), O._dp(m), O._dp(acc), 0.001, 0.1 ** 2, 0.01, steps)
     dt = time.perf_counter() - t0
+    # the reference's own (materialised N x N x D torch) formulation cannot reach N = 65536; time it at
+    # the largest comfortable size on the same cores for context (SURVEY.md section 8d CPU baseline (ii))
+    ref_form = None
+    try:
+        import torch
+        from oracle import torch_materialised as TM
+        nr = 4096
+        rt, threads = TM.time_steps(pos[:nr].clone(), vel[:nr].clone(), mass[:nr].clone(), steps=5, warmup=1,
+                                    threads=os.cpu_count())
+        ref_form = {"value": nr * 5 / rt, "unit": "particle-steps/s", "n": nr, "threads": threads,
+                    "pair_interactions_per_s": float(nr) * nr * 5 / rt,
+                    "what": "reference formulation (materialised torch broadcasts, simulation.py:74-143) restated in "
+                            "oracle/torch_materialised.py, FLOAT64 mode, 5 steps"}
+    except Exception as exc:            # never let the context measurement break the bench line
+        ref_form = {"error": repr(exc)}
     return {
+        "reference_formulation_torch_cpu": ref_form,
         "value": n * steps / dt, "unit": "particle-steps/s", "cores": O.num_threads(), "kind": "port",
         "sample": f"N={n} fp64 disk galaxy, {steps} leapfrog steps of the oracle's OpenMP fast path "
                   f"({dt:.1f} s; the reference's own PyTorch formulation cannot run at this N)",

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnbody_amd.so")
+# NBODY_LIB: load an alternative build of the same C-ABI (A/B experiments: `make exp EXPFLAGS=-D...`)
+LIB_PATH = os.environ.get("NBODY_LIB") or os.path.join(_HERE, "libnbody_amd.so")
 
 NB_F16, NB_BF16, NB_F32, NB_F64 = 0, 1, 2, 3
 NB_FLAG_PROFILE = 1

@@ -46,7 +46,11 @@ __device__ __forceinline__ float rot1<float>(float v, int addr)
 //       compiler re-materialises 1.5 with two v_mov per pair (v_fmac needs it in the destination).
 __device__ __forceinline__ double inv_r3_sym(double q, double c15, double c1875)
 {
+#ifdef NB_EXP_RSQ_F32
+    const double y0 = (double)__builtin_amdgcn_rsqf((float)q);   // experiment: fp32 seed via two converts
+#else
     const double y0 = __builtin_amdgcn_rsq(q);
+#endif
     const double y02 = y0 * y0;
     const double e = __builtin_fma(-q, y02, 1.0);
     const double v = y0 * y02;

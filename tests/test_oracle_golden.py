@@ -263,3 +263,23 @@ def test_j_range_partials_sum_to_full():
     p64 = sum(O.accelerations_f64_fast(pos.astype(np.float64), mass.astype(np.float64), softening=0.05, j_range=r)
               for r in ((0, 128), (128, n)))
     assert relerr(p64, f64) < 1e-14
+
+
+@pytest.mark.parametrize("mode", ["float64", "float32", "bfloat16", "float16"])
+def test_torch_materialised_restatement_agrees(mode):
+    """oracle/torch_materialised.py (used by bench.py as 'the reference's PyTorch-CPU path') reproduces the
+    golden trajectory bit for bit in FLOAT64 mode and agrees with the C oracle in the cast modes."""
+    import torch
+    from oracle import torch_materialised as TM
+    g = load_golden("g2_config1_n1024.npz")
+    pos, vel, m = (torch.from_numpy(g[k]) for k in ("pos", "vel", "mass"))
+    st = dict(pos=pos, vel=vel, masses=m)
+    st["acc"] = TM.accelerations(pos, m, mode=mode)
+    for _ in range(10):
+        TM.step(st, mode=mode)
+    ref = g[f"{mode}/pos10"]
+    assert st["pos"].numpy().dtype == ref.dtype
+    if mode == "float64":
+        assert np.array_equal(st["pos"].numpy(), ref)
+    else:
+        assert relerr(st["pos"].numpy(), ref) < 1e-6
