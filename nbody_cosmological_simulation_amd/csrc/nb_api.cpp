@@ -212,31 +212,39 @@ int build_sym_plan(nb_sim *s)
         if ((r == 1 && s->is_f64) || r == 2 || (r == 4 && c.dim == 2)) sp.r = r;
     }
     sp.tile_b = 64 * sp.r;
-    sp.tiles = (c.n + sp.tile_b - 1) / sp.tile_b;
+    const int Treal = (c.n + sp.tile_b - 1) / sp.tile_b;      // tiles that hold particles
+    const int SR = (Treal + 3) / 4;                            // super-rows of four target tiles
+    sp.tiles = SR * 4;                                         // padded tile count
     sp.np = sp.tiles * sp.tile_b;
-    const int T = sp.tiles, P = c.nranks;
-    std::vector<int> owner(T), ord(T, -1), slot0(T, 0), nslots(T, 0);
+    const int T = Treal, P = c.nranks;
+    std::vector<int> ord(SR, -1), slot0(sp.tiles, 0), nslots(sp.tiles, 0);
     long long owned_pairs = 0;
     int nrows = 0;
-    for (int I = 0; I < T; ++I) {
-        const int k = I % (2 * P);
-        owner[I] = k < P ? k : 2 * P - 1 - k;
-        if (owner[I] == c.rank) { ord[I] = nrows++; owned_pairs += T - I; }
+    for (int S = 0; S < SR; ++S) {
+        const int k = S % (2 * P);
+        const int owner = k < P ? k : 2 * P - 1 - k;           // snake: equal pair counts per rank
+        if (owner == c.rank) {
+            ord[S] = nrows++;
+            for (int w = 0; w < 4; ++w) owned_pairs += std::max(0, T - (4 * S + w));
+        }
     }
-    // ~6000 workgroups per launch: measured at N=65536 (R=4) cl = 4/8/16/32/64 -> 1.27/1.26/1.29/1.38/1.52 ms
-    int cl = (int)((owned_pairs / 6144 + 3) / 4 * 4);
-    cl = std::max(4, std::min(cl, 64));
-    if (const char *e = getenv("NB_SYM_CL")) cl = std::max(4, atoi(e) / 4 * 4);
+    // ~6000 workgroups per launch: measured at N=65536 (R=4): 4/8/16/32/64 source tiles per wave-set
+    // -> 1.27/1.26/1.29/1.38/1.52 ms.  A workgroup sweeps 4 rows x cl source tiles.
+    int cl = (int)(owned_pairs / 6144 / 4);
+    cl = std::max(1, std::min(cl, 16));
+    if (const char *e = getenv("NB_SYM_CL")) cl = std::max(1, atoi(e));
     std::vector<SymWork> work;
     int slots = 0;
-    for (int I = 0; I < T; ++I) {
-        if (ord[I] < 0) continue;
-        slot0[I] = slots;
-        for (int jb = I; jb < T; jb += cl) {
-            SymWork w{I, jb, std::min(T, jb + cl), slots++, ord[I]};
-            work.push_back(w);
+    for (int S = 0; S < SR; ++S) {
+        if (ord[S] < 0) continue;
+        const int j0 = 4 * S;
+        const int nch = (T - j0 + cl - 1) / cl;
+        for (int w = 0; w < 4; ++w) { slot0[j0 + w] = slots + w * nch; nslots[j0 + w] = nch; }
+        for (int ch = 0; ch < nch; ++ch) {
+            SymWork wk{j0, j0 + ch * cl, std::min(T, j0 + (ch + 1) * cl), slots + ch, nch, ord[S]};
+            work.push_back(wk);
         }
-        nslots[I] = slots - slot0[I];
+        slots += 4 * nch;
     }
     std::stable_sort(work.begin(), work.end(), [](const SymWork &a, const SymWork &b) {
         return (a.jt_end - a.jt_begin) > (b.jt_end - b.jt_begin);
@@ -249,16 +257,16 @@ int build_sym_plan(nb_sim *s)
     sp.nrows = nrows;
     if (sp.nwork == 0) return NB_OK;
     HIPCHK(hipMalloc((void **)&sp.work, work.size() * sizeof(SymWork)));
-    HIPCHK(hipMalloc((void **)&sp.row_slot0, T * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&sp.row_nslots, T * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&sp.row_ord, T * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&sp.row_slot0, sp.tiles * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&sp.row_nslots, sp.tiles * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&sp.row_ord, SR * sizeof(int)));
     HIPCHK(hipMalloc((void **)&sp.packed, (size_t)(c.dim + 1) * sp.np * el));
     HIPCHK(hipMalloc((void **)&sp.rowslab, (size_t)c.dim * sp.tile_b * sizeof(double) * (size_t)std::max(slots, 1)));
     HIPCHK(hipMalloc((void **)&sp.colslab, col_bytes));
     HIPCHK(hipMemcpy(sp.work, work.data(), work.size() * sizeof(SymWork), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp.row_slot0, slot0.data(), T * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp.row_nslots, nslots.data(), T * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp.row_ord, ord.data(), T * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp.row_slot0, slot0.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp.row_nslots, nslots.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp.row_ord, ord.data(), SR * sizeof(int), hipMemcpyHostToDevice));
     sp.enabled = true;
     return NB_OK;
 }

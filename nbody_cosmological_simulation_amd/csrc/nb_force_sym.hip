@@ -15,8 +15,11 @@
 //   data and the J accumulators rotate by one lane (ds_bpermute_b32: the LDS crossbar, no VALU
 //   cycles), so every lane meets every J particle once and the accumulators return home.
 //   J == I (diagonal tile) is evaluated one-sided, so each ordered pair is counted once.
-//   Outputs go to per-(row chunk) and per-(row) slabs that reduce_sym_kernel adds in a fixed
-//   order: no atomics, run-to-run bit-identical.
+//   A workgroup = four waves = four consecutive target tiles (a "super-row") walking the SAME
+//   source tiles in step; after each source tile the four waves' column sums are added through
+//   LDS in a fixed order, so one column slab per super-row leaves the chip (4x less slab traffic
+//   than one per row).  Row sums go to per-(row, chunk) slots.  reduce_sym_kernel adds slots and
+//   slabs in a fixed order: no atomics, run-to-run bit-identical.
 #include "nb_internal.h"
 
 #include <type_traits>
@@ -180,18 +183,20 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
 //                          padding particles sit far away (see pack_kernel).
 // rowslab [slot][D][B] fp64 (one target tile per workgroup slot), colslab [row][D][NP] of T.
 template <typename T, int D, int R, bool UNIFORM, int HOOK>
-__global__ void __launch_bounds__(NB_BLOCK)
+__global__ void __launch_bounds__(NB_BLOCK, 4)      // <= 128 VGPRs: four waves per SIMD
 force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work, double *__restrict__ rowslab,
                  T *__restrict__ colslab, int np, T eps2, const GridTables *__restrict__ tab, float gfac)
 {
     constexpr int B = 64 * R;
+    constexpr int W = NB_BLOCK / 64;
     constexpr bool F32 = std::is_same_v<T, float>;
-    __shared__ double s_ai[NB_BLOCK / 64][R][D][64];
+    __shared__ T s_aj[W][R][D][64];
     __shared__ float s_thr[HOOK == HOOK_GRID ? NB_MAX_LUT + 1 : 1];
     __shared__ float s_lut[HOOK == HOOK_GRID ? NB_MAX_LUT : 1];
 
     const SymWork wk = work[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int I = wk.tile_i + wave;             // this wave's target tile (wave-uniform)
     const int rot_addr = ((lane + 1) & 63) << 2;
     GridArgs ga{s_thr, s_lut, 0.0f, 0.0f, gfac, 0, false};
     bool use_est = false;
@@ -214,7 +219,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
     double ai_sum[R][D];      // fp64 running sums over the whole chunk (fp32: folded per tile)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int p = wk.tile_i * B + r * 64 + lane;
+        const int p = I * B + r * 64 + lane;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             xi[r][k] = packed[(size_t)k * np + p];
@@ -223,56 +228,63 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
         gi[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
     }
 
-    for (int J = wk.jt_begin + wave; J < wk.jt_end; J += NB_BLOCK / 64) {
-        T xj[R][D], gj[R], aj[R][D], ai[R][D];
+    for (int J = wk.jt_begin; J < wk.jt_end; ++J) {     // all four waves take the same source tile
+        T aj[R][D];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int p = J * B + r * 64 + lane;
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                xj[r][k] = packed[(size_t)k * np + p];
-                aj[r][k] = (T)0;
-                ai[r][k] = F32 ? (T)0 : (T)ai_sum[r][k];
-            }
-            gj[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
-        }
-        const bool diag = (J == wk.tile_i);     // wave-uniform
-        if (HOOK == HOOK_GRID && use_est) {
-            if (diag) sweep<T, D, R, true, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
-            else sweep<T, D, R, false, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
-        } else {
-            if (diag) sweep<T, D, R, true, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
-            else sweep<T, D, R, false, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
-        }
-        if (!diag) {
-            // column contributions of row I to the particles of tile J (accumulators are home again)
+            for (int k = 0; k < D; ++k) aj[r][k] = (T)0;
+        if (J >= I) {                                   // wave-uniform; tiles below the diagonal belong to other rows
+            T xj[R][D], gj[R], ai[R][D];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int p = J * B + r * 64 + lane;
 #pragma unroll
-                for (int k = 0; k < D; ++k) colslab[((size_t)wk.row_ord * D + k) * np + p] = aj[r][k];
+                for (int k = 0; k < D; ++k) {
+                    xj[r][k] = packed[(size_t)k * np + p];
+                    ai[r][k] = F32 ? (T)0 : (T)ai_sum[r][k];
+                }
+                gj[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
             }
+            const bool diag = (J == I);
+            if (HOOK == HOOK_GRID && use_est) {
+                if (diag) sweep<T, D, R, true, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
+                else sweep<T, D, R, false, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
+            } else {
+                if (diag) sweep<T, D, R, true, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
+                else sweep<T, D, R, false, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int k = 0; k < D; ++k) ai_sum[r][k] = F32 ? ai_sum[r][k] + (double)ai[r][k] : (double)ai[r][k];
         }
+        // column contributions of the super-row to tile J: the diagonal sweep leaves aj untouched (0),
+        // skipped waves hold 0; add the four waves in a fixed order and write ONE slab entry
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int k = 0; k < D; ++k) ai_sum[r][k] = F32 ? ai_sum[r][k] + (double)ai[r][k] : (double)ai[r][k];
+            for (int k = 0; k < D; ++k) s_aj[wave][r][k][lane] = aj[r][k];
+        __syncthreads();
+        if (J > wk.tile_i) {                            // block-uniform: at least the first row lies below J
+            for (int idx = threadIdx.x; idx < R * D * 64; idx += NB_BLOCK) {
+                const int l = idx & 63, rk = idx >> 6;
+                const int r = rk / D, k = rk % D;
+                T v = s_aj[0][r][k][l];
+#pragma unroll
+                for (int w = 1; w < W; ++w) v += s_aj[w][r][k][l];
+                colslab[((size_t)wk.row_ord * D + k) * np + (size_t)J * B + r * 64 + l] = v;
+            }
+        }
+        __syncthreads();
     }
 
-    // combine the four waves' row sums in a fixed order and write one slab slot per workgroup
+    // row sums: one compact slot per (row, chunk)
+    const int slot = wk.slot + wave * wk.slot_stride;
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int k = 0; k < D; ++k) s_ai[wave][r][k][lane] = ai_sum[r][k];
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < R * D * 64; idx += NB_BLOCK) {
-        const int l = idx & 63, rk = idx >> 6;
-        const int r = rk / D, k = rk % D;
-        double v = s_ai[0][r][k][l];
-#pragma unroll
-        for (int w = 1; w < NB_BLOCK / 64; ++w) v += s_ai[w][r][k][l];
-        rowslab[((size_t)wk.slot * D + k) * B + r * 64 + l] = v;      // compact: one tile per slot
-    }
+        for (int k = 0; k < D; ++k) rowslab[((size_t)slot * D + k) * B + r * 64 + lane] = ai_sum[r][k];
 }
 
 // Padding particles sit at PAD in every coordinate: r^2 stays finite, y0^3 underflows to exactly
@@ -320,7 +332,7 @@ pack_kernel(T *__restrict__ pos, T *__restrict__ vel, const T *__restrict__ acc,
     }
 }
 
-// acc[p] = sum of the row slots of p's tile + sum over rows I < tile(p) of the column slabs,
+// acc[p] = sum of the row slots of p's tile + sum over the super-rows at or above tile(p) of the column slabs,
 // always in the same order.  Block = 64 particles x 4 waves: wave g adds rows I = g, g+4, ...
 // (four loads in flight per lane), the four partial sums are combined in the order g = 0..3
 // through LDS -> still one fixed summation tree.  Optionally fuses the closing half kick
@@ -340,16 +352,22 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
     double s[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) s[k] = 0.0;
-    if (g == 0) {
+    {
+        // row slots of this tile (one per source chunk), dealt over the four waves like the slabs
         const int s0 = row_slot0[J], ns = row_nslots[J];
         const int off = pc - J * tile_b;
-        for (int c = 0; c < ns; ++c)
+#pragma unroll 4
+        for (int c = g; c < ns; c += NB_BLOCK / 64)
 #pragma unroll
             for (int k = 0; k < D; ++k) s[k] += rowslab[((size_t)(s0 + c) * D + k) * tile_b + off];
     }
+    // column slabs: super-rows (four target tiles each) strictly above tile J, plus J's own
+    // super-row when J is not its first tile
+    const int SJ = J >> 2;
+    const int nsr = SJ + (((J & 3) > 0) ? 1 : 0);
 #pragma unroll 4
-    for (int I = g; I < J; I += NB_BLOCK / 64) {
-        const int ord = row_ord[I];
+    for (int SI = g; SI < nsr; SI += NB_BLOCK / 64) {
+        const int ord = row_ord[SI];
         if (ord >= 0) {
 #pragma unroll
             for (int k = 0; k < D; ++k) s[k] += (double)colslab[((size_t)ord * D + k) * np + pc];
@@ -387,18 +405,19 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
     __shared__ double s_red[NB_BLOCK / 64];
     const SymWork wk = work[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int I = wk.tile_i + wave;
     const int rot_addr = ((lane + 1) & 63) << 2;
 
     T xi[R][D], mi[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int p = wk.tile_i * B + r * 64 + lane;
+        const int p = I * B + r * 64 + lane;
 #pragma unroll
         for (int k = 0; k < D; ++k) xi[r][k] = packed[(size_t)k * np + p];
         mi[r] = packed[(size_t)D * np + p];
     }
     double sum = 0.0;
-    for (int J = wk.jt_begin + wave; J < wk.jt_end; J += NB_BLOCK / 64) {
+    for (int J = max(wk.jt_begin, I); J < wk.jt_end; ++J) {
         T xj[R][D], mj[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -407,7 +426,7 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
             for (int k = 0; k < D; ++k) xj[r][k] = packed[(size_t)k * np + p];
             mj[r] = packed[(size_t)D * np + p];
         }
-        const bool diag = (J == wk.tile_i);
+        const bool diag = (J == I);
         double tsum[R];             // independent chains: a single accumulator would serialise the adds
 #pragma unroll
         for (int r = 0; r < R; ++r) tsum[r] = 0.0;

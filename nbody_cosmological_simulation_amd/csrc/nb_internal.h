@@ -49,13 +49,15 @@ struct ForceGeom {
     int r;          // targets per thread
 };
 
-// One workgroup of the pair-symmetric kernel: target tile `tile_i` against source tiles
-// [jt_begin, jt_end) (jt_begin >= tile_i; the four waves take them round-robin).
+// One workgroup of the pair-symmetric kernels: the super-row of target tiles
+// [tile_i, tile_i + 4) (one per wave) against source tiles [jt_begin, jt_end); a wave skips the
+// source tiles below its own target tile.
 struct SymWork {
-    int tile_i;
+    int tile_i;        // first target tile of the super-row (multiple of 4)
     int jt_begin, jt_end;
-    int slot;      // row-slab slot this workgroup writes its target-tile sums to
-    int row_ord;   // ordinal of row tile_i among the rows this rank owns (column-slab index)
+    int slot;          // row-slab slot of wave 0 for this chunk; wave w uses slot + w * slot_stride
+    int slot_stride;   // = number of chunks of this super-row
+    int row_ord;       // ordinal of the super-row among those this rank owns (column-slab index)
 };
 
 // pack positions + mass factors into padded component arrays; kick != 0 fuses the opening
