@@ -71,6 +71,10 @@ typedef struct nb_config {
                                      PARTIAL sums (no all-reduce, no force quantisation) for the caller
                                      to reduce; nb_step is refused.  Used by single-GPU shard tests.   */
 
+#define NB_FLAG_SHARD_TIMING   8   /* timing experiments on ONE GPU: compute only shard `rank` of `nranks`
+                                     but run the collectives on a 1-rank communicator.  Results are
+                                     partial sums -- never use for physics.                            */
+
 /* ---- lifetime ------------------------------------------------------------------------ */
 
 /* GalaxySimulation.__init__ (simulation.py:31-72) minus the state upload and first force. */

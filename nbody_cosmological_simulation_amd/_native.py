@@ -15,6 +15,7 @@ NB_F16, NB_BF16, NB_F32, NB_F64 = 0, 1, 2, 3
 NB_FLAG_PROFILE = 1
 NB_FLAG_CUSTOM_FORCEQ = 2
 NB_FLAG_NO_COMM = 4
+NB_FLAG_SHARD_TIMING = 8
 
 MODE_CODES = {
     "float64": 0, "float32": 1, "bfloat16": 2, "float16": 3,

@@ -138,7 +138,7 @@ struct nb_sim {
     // pair-symmetric fp64 path (nb_force_sym.hip)
     struct SymPlan {
         bool enabled = false;
-        int r = 2, tile_b = 128, tiles = 0, np = 0, nwork = 0, nslots = 0, nrows = 0;
+        int r = 2, tile_b = 128, tiles = 0, np = 0, nwork = 0, nslots = 0, nrows = 0, nsplit = 1;
         SymWork *work = nullptr;
         int *row_slot0 = nullptr, *row_nslots = nullptr, *row_ord = nullptr;
         void *packed = nullptr, *colslab = nullptr;   // storage type of the state (fp32 or fp64)
@@ -233,24 +233,40 @@ int build_sym_plan(nb_sim *s)
     int cl = (int)(owned_pairs / 6144 / 4);
     cl = std::max(1, std::min(cl, 16));
     if (const char *e = getenv("NB_SYM_CL")) cl = std::max(1, atoi(e));
+    // When a rank owns few work items (multi-GPU at moderate N) whole sweeps are too coarse to fill
+    // 1024 SIMDs evenly: a sweep's 64 rotation steps are then cut into nsplit independent pieces
+    // (a piece starts with the source tile pre-rotated, see force_sym_kernel).
+    long long items = 0;
+    for (int S = 0; S < SR; ++S)
+        if (ord[S] >= 0) items += (T - 4 * S + cl - 1) / cl;
+    // Measured (one GPU standing in for rank 0 of 8, N=65536): nsplit 1 -> 4 takes the force kernel from
+    // 0.206 to 0.189 ms but the 4x larger slab/slot reduction costs more than that (step 0.230 -> 0.241 ms),
+    // so whole sweeps stay the default; NB_SYM_SPLIT forces 2 or 4 for experiments.
+    (void)items;
+    int nsplit = 1;
+    if (const char *e = getenv("NB_SYM_SPLIT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nsplit = v; }
+    sp.nsplit = nsplit;
     std::vector<SymWork> work;
     int slots = 0;
     for (int S = 0; S < SR; ++S) {
         if (ord[S] < 0) continue;
         const int j0 = 4 * S;
         const int nch = (T - j0 + cl - 1) / cl;
-        for (int w = 0; w < 4; ++w) { slot0[j0 + w] = slots + w * nch; nslots[j0 + w] = nch; }
-        for (int ch = 0; ch < nch; ++ch) {
-            SymWork wk{j0, j0 + ch * cl, std::min(T, j0 + (ch + 1) * cl), slots + ch, nch, ord[S]};
-            work.push_back(wk);
-        }
-        slots += 4 * nch;
+        const int per_row = nch * nsplit;
+        for (int w = 0; w < 4; ++w) { slot0[j0 + w] = slots + w * per_row; nslots[j0 + w] = per_row; }
+        for (int ch = 0; ch < nch; ++ch)
+            for (int q = 0; q < nsplit; ++q) {
+                SymWork wk{j0, j0 + ch * cl, std::min(T, j0 + (ch + 1) * cl), slots + ch * nsplit + q, per_row,
+                           ord[S] * nsplit + q, q * (64 / nsplit), 64 / nsplit};
+                work.push_back(wk);
+            }
+        slots += 4 * per_row;
     }
     std::stable_sort(work.begin(), work.end(), [](const SymWork &a, const SymWork &b) {
         return (a.jt_end - a.jt_begin) > (b.jt_end - b.jt_begin);
     });
     const size_t el = s->is_f64 ? sizeof(double) : sizeof(float);
-    const size_t col_bytes = (size_t)c.dim * sp.np * el * (size_t)std::max(nrows, 1);
+    const size_t col_bytes = (size_t)c.dim * sp.np * el * (size_t)std::max(nrows, 1) * nsplit;
     if (col_bytes > (size_t)48 << 30) return NB_OK;       // fall back to the one-sided kernel
     sp.nwork = (int)work.size();
     sp.nslots = slots;
@@ -505,8 +521,9 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         // uniform-mass kernels leave out the mass factor: G*m in T arithmetic (fp32: (float)G * m)
         double scale = 1.0;
         if (sym_uniform) scale = s->is_f64 ? c.G * s->mass_value : (double)((float)c.G * (float)s->mass_value);
-        HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.row_ord, sp.tile_b, c.n,
-                                    sp.np, c.dim, s->is_f64, scale, s->acc, s->vel, half_dt, fuse_kick, s->stream));
+        HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.row_ord, sp.nsplit,
+                                    sp.tile_b, c.n, sp.np, c.dim, s->is_f64, scale, s->acc, s->vel, half_dt, fuse_kick,
+                                    s->stream));
     } else {
         HIPCHK(nb_launch_reduce(s->partial, s->geom.nchunks, cnt, s->acc, s->is_f64, s->vel, half_dt, fuse_kick,
                                 s->stream));
@@ -938,7 +955,10 @@ int nb_comm_init(nb_sim *s, const void *id, int32_t id_bytes)
     DeviceGuard guard(s->cfg.device);
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
-    NCCLCHK(g_rccl.CommInitRank(&s->comm, s->cfg.nranks, uid, s->cfg.rank));
+    if (s->cfg.flags & NB_FLAG_SHARD_TIMING)       // one process stands in for one of nranks shards
+        NCCLCHK(g_rccl.CommInitRank(&s->comm, 1, uid, 0));
+    else
+        NCCLCHK(g_rccl.CommInitRank(&s->comm, s->cfg.nranks, uid, s->cfg.rank));
     return NB_OK;
 }
 

@@ -108,12 +108,13 @@ struct GridArgs {
 
 template <typename T, int D, int R, bool DIAG, bool UNIFORM, int HOOK, bool EST>
 __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (&ai)[R][D], T (&xj)[R][D],
-                                      T (&gj)[R], T (&aj)[R][D], T eps2, int rot_addr, const GridArgs &ga)
+                                      T (&gj)[R], T (&aj)[R][D], T eps2, int rot_addr, const GridArgs &ga,
+                                      int nsteps)
 {
     T c15 = (T)1.5, c1875 = (T)1.875;
     if constexpr (std::is_same_v<T, double>) asm volatile("" : "+v"(c15), "+s"(c1875));
 #pragma unroll 1
-    for (int s = 0; s < 64; ++s) {
+    for (int s = 0; s < nsteps; ++s) {
         // source slot outermost: once all targets have met source rj its data and accumulator are
         // final for this step, so their rotation is issued at once and overlaps the remaining slots
 #pragma unroll
@@ -238,7 +239,8 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
             T xj[R][D], gj[R], ai[R][D];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int p = J * B + r * 64 + lane;
+                // a split sweep starts s_begin rotation steps in: lane l meets particle (l + s_begin) first
+                const int p = J * B + r * 64 + ((lane + wk.s_begin) & 63);
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
                     xj[r][k] = packed[(size_t)k * np + p];
@@ -248,11 +250,11 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
             }
             const bool diag = (J == I);
             if (HOOK == HOOK_GRID && use_est) {
-                if (diag) sweep<T, D, R, true, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
-                else sweep<T, D, R, false, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
+                if (diag) sweep<T, D, R, true, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                else sweep<T, D, R, false, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
             } else {
-                if (diag) sweep<T, D, R, true, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
-                else sweep<T, D, R, false, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga);
+                if (diag) sweep<T, D, R, true, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                else sweep<T, D, R, false, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -260,11 +262,13 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                 for (int k = 0; k < D; ++k) ai_sum[r][k] = F32 ? ai_sum[r][k] + (double)ai[r][k] : (double)ai[r][k];
         }
         // column contributions of the super-row to tile J: the diagonal sweep leaves aj untouched (0),
-        // skipped waves hold 0; add the four waves in a fixed order and write ONE slab entry
+        // skipped waves hold 0; add the four waves in a fixed order and write ONE slab entry.
+        // After s_count rotations lane l holds the accumulators of particle (l + s_begin + s_count).
+        const int home = (lane + wk.s_begin + wk.s_count) & 63;
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int k = 0; k < D; ++k) s_aj[wave][r][k][lane] = aj[r][k];
+            for (int k = 0; k < D; ++k) s_aj[wave][r][k][home] = aj[r][k];
         __syncthreads();
         if (J > wk.tile_i) {                            // block-uniform: at least the first row lies below J
             for (int idx = threadIdx.x; idx < R * D * 64; idx += NB_BLOCK) {
@@ -273,7 +277,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                 T v = s_aj[0][r][k][l];
 #pragma unroll
                 for (int w = 1; w < W; ++w) v += s_aj[w][r][k][l];
-                colslab[((size_t)wk.row_ord * D + k) * np + (size_t)J * B + r * 64 + l] = v;
+                colslab[((size_t)wk.col_ord * D + k) * np + (size_t)J * B + r * 64 + l] = v;
             }
         }
         __syncthreads();
@@ -341,8 +345,8 @@ template <typename T, int D>
 __global__ void __launch_bounds__(NB_BLOCK)
 reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ colslab,
                   const int *__restrict__ row_slot0, const int *__restrict__ row_nslots,
-                  const int *__restrict__ row_ord, int tile_b, int n, int np, double scale, T *__restrict__ acc,
-                  T *__restrict__ vel, T half_dt, int do_kick)
+                  const int *__restrict__ row_ord, int nsplit, int tile_b, int n, int np, double scale,
+                  T *__restrict__ acc, T *__restrict__ vel, T half_dt, int do_kick)
 {
     __shared__ double s_part[NB_BLOCK / 64][D][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -369,8 +373,9 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
     for (int SI = g; SI < nsr; SI += NB_BLOCK / 64) {
         const int ord = row_ord[SI];
         if (ord >= 0) {
+            for (int q = 0; q < nsplit; ++q)
 #pragma unroll
-            for (int k = 0; k < D; ++k) s[k] += (double)colslab[((size_t)ord * D + k) * np + pc];
+                for (int k = 0; k < D; ++k) s[k] += (double)colslab[((size_t)(ord * nsplit + q) * D + k) * np + pc];
         }
     }
 #pragma unroll
@@ -421,7 +426,7 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
         T xj[R][D], mj[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int p = J * B + r * 64 + lane;
+            const int p = J * B + r * 64 + ((lane + wk.s_begin) & 63);
 #pragma unroll
             for (int k = 0; k < D; ++k) xj[r][k] = packed[(size_t)k * np + p];
             mj[r] = packed[(size_t)D * np + p];
@@ -431,7 +436,7 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
 #pragma unroll
         for (int r = 0; r < R; ++r) tsum[r] = 0.0;
 #pragma unroll 1
-        for (int s = 0; s < 64; ++s) {
+        for (int s = wk.s_begin; s < wk.s_begin + wk.s_count; ++s) {
 #pragma unroll
             for (int ri = 0; ri < R; ++ri) {
 #pragma unroll
@@ -573,14 +578,14 @@ hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int 
 }
 
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
-                                const int *row_nslots, const int *row_ord, int tile_b, int n, int np, int dim,
-                                int is_f64, double scale, void *acc, void *vel, double half_dt, int do_kick,
-                                hipStream_t st)
+                                const int *row_nslots, const int *row_ord, int nsplit, int tile_b, int n, int np,
+                                int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
+                                int do_kick, hipStream_t st)
 {
     const int grid = (n + 63) / 64;
 #define NB_RED(TT, DD) \
     hipLaunchKernelGGL((reduce_sym_kernel<TT, DD>), dim3(grid), dim3(NB_BLOCK), 0, st, rowslab, (const TT *)colslab, \
-                       row_slot0, row_nslots, row_ord, tile_b, n, np, scale, (TT *)acc, (TT *)vel, (TT)half_dt, do_kick)
+                       row_slot0, row_nslots, row_ord, nsplit, tile_b, n, np, scale, (TT *)acc, (TT *)vel, (TT)half_dt, do_kick)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64) { if (dim == 2) NB_RED(double, 2); else NB_RED(double, 3); }
     else        { if (dim == 2) NB_RED(float, 2); else NB_RED(float, 3); }

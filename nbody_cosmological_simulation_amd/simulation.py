@@ -70,6 +70,11 @@ class GalaxySimulation:
         self._native_acc = None
         rank, world = runtime.rank_world()
         flags = N.NB_FLAG_PROFILE if profile else 0
+        import os
+        fake = os.environ.get("NBODY_SHARD_TIMING")       # "r/P": time one shard of P on a single GPU
+        if fake and shard is None and runtime.force_comm():
+            rank, world = (int(v) for v in fake.split("/"))
+            flags |= N.NB_FLAG_SHARD_TIMING
         if shard is not None:
             # explicit (rank, world) without a communicator: this handle only produces the partial
             # sums of its source block (single-GPU shard tests / caller-side reduction)
