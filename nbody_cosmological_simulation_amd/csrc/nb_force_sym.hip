@@ -183,8 +183,10 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
 // packed  [D+1][NP] of T : x, y, (z), mass factor (G*m, or m for HOOK_GRID whose LUT carries G);
 //                          padding particles sit far away (see pack_kernel).
 // rowslab [slot][D][B] fp64 (one target tile per workgroup slot), colslab [row][D][NP] of T.
+// <= 128 VGPRs: four waves per SIMD.  (Five waves -- 96 VGPRs -- were measured too: no gain at any
+// shard count, and the general-mass kernel starts to spill.)
 template <typename T, int D, int R, bool UNIFORM, int HOOK>
-__global__ void __launch_bounds__(NB_BLOCK, 4)      // <= 128 VGPRs: four waves per SIMD
+__global__ void __launch_bounds__(NB_BLOCK, 4)
 force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work, double *__restrict__ rowslab,
                  T *__restrict__ colslab, int np, T eps2, const GridTables *__restrict__ tab, float gfac)
 {
