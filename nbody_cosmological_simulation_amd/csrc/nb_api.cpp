@@ -140,7 +140,7 @@ struct nb_sim {
         bool enabled = false;
         int r = 2, tile_b = 128, tiles = 0, np = 0, nwork = 0, nslots = 0, nrows = 0, nsplit = 1;
         SymWork *work = nullptr;
-        int *row_slot0 = nullptr, *row_nslots = nullptr, *row_ord = nullptr;
+        int *row_slot0 = nullptr, *row_nslots = nullptr, *col_base = nullptr, *col_count = nullptr;
         void *packed = nullptr, *colslab = nullptr;   // storage type of the state (fp32 or fp64)
         double *rowslab = nullptr;
     } sym;
@@ -233,40 +233,57 @@ int build_sym_plan(nb_sim *s)
     int cl = (int)(owned_pairs / 6144 / 4);
     cl = std::max(1, std::min(cl, 16));
     if (const char *e = getenv("NB_SYM_CL")) cl = std::max(1, atoi(e));
-    // When a rank owns few work items (multi-GPU at moderate N) whole sweeps are too coarse to fill
-    // 1024 SIMDs evenly: a sweep's 64 rotation steps are then cut into nsplit independent pieces
-    // (a piece starts with the source tile pre-rotated, see force_sym_kernel).
+    // Tail smoothing.  Work items (4 rows x cl source tiles) all take the same time and the chip runs
+    // `slots` workgroups at once (4 per CU at <= 128 VGPRs), so items beyond a multiple of `slots` cost
+    // a whole extra round on a few CUs (measured: 1040 items on 1024 slots -> 0.21 instead of 0.16 ms).
+    // The sweeps of just enough trailing super-rows are therefore cut into 4 pieces of 16 rotation
+    // steps (a piece starts with the source tile pre-rotated, see force_sym_kernel); only those
+    // super-rows pay the extra slab / slot traffic.
+    int dev_cus = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) dev_cus = prop.multiProcessorCount; }
+    const long long wg_slots = 4LL * dev_cus;
+    std::vector<int> nch_of(SR, 0), split_of(SR, 1);
     long long items = 0;
     for (int S = 0; S < SR; ++S)
-        if (ord[S] >= 0) items += (T - 4 * S + cl - 1) / cl;
-    // Measured (one GPU standing in for rank 0 of 8, N=65536): nsplit 1 -> 4 takes the force kernel from
-    // 0.206 to 0.189 ms but the 4x larger slab/slot reduction costs more than that (step 0.230 -> 0.241 ms),
-    // so whole sweeps stay the default; NB_SYM_SPLIT forces 2 or 4 for experiments.
-    (void)items;
-    int nsplit = 1;
-    if (const char *e = getenv("NB_SYM_SPLIT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nsplit = v; }
-    sp.nsplit = nsplit;
+        if (ord[S] >= 0) { nch_of[S] = (T - 4 * S + cl - 1) / cl; items += nch_of[S]; }
+    int force_split = 0;
+    if (const char *e = getenv("NB_SYM_SPLIT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) force_split = v; }
+    if (force_split) {
+        for (int S = 0; S < SR; ++S) split_of[S] = force_split;
+    } else if (items > wg_slots / 2) {
+        long long rem = items % wg_slots;
+        if (rem > 0 && rem <= wg_slots / 2) {
+            for (int S = SR - 1; S >= 0 && rem > 0; --S)      // trailing (shortest) super-rows first
+                if (ord[S] >= 0) { split_of[S] = 4; rem -= nch_of[S]; }
+        }
+    }
+    sp.nsplit = 1;
     std::vector<SymWork> work;
-    int slots = 0;
+    std::vector<int> col_base(SR, 0), col_count(SR, 0);
+    int slots = 0, ncol = 0;
     for (int S = 0; S < SR; ++S) {
         if (ord[S] < 0) continue;
         const int j0 = 4 * S;
-        const int nch = (T - j0 + cl - 1) / cl;
-        const int per_row = nch * nsplit;
+        const int nch = nch_of[S], nsp = split_of[S];
+        const int per_row = nch * nsp;
+        col_base[S] = ncol;
+        col_count[S] = nsp;
         for (int w = 0; w < 4; ++w) { slot0[j0 + w] = slots + w * per_row; nslots[j0 + w] = per_row; }
         for (int ch = 0; ch < nch; ++ch)
-            for (int q = 0; q < nsplit; ++q) {
-                SymWork wk{j0, j0 + ch * cl, std::min(T, j0 + (ch + 1) * cl), slots + ch * nsplit + q, per_row,
-                           ord[S] * nsplit + q, q * (64 / nsplit), 64 / nsplit};
+            for (int q = 0; q < nsp; ++q) {
+                SymWork wk{j0, j0 + ch * cl, std::min(T, j0 + (ch + 1) * cl), slots + ch * nsp + q, per_row,
+                           ncol + q, q * (64 / nsp), 64 / nsp};
                 work.push_back(wk);
             }
         slots += 4 * per_row;
+        ncol += nsp;
     }
+    // whole sweeps first, pieces last (longest processing time first)
     std::stable_sort(work.begin(), work.end(), [](const SymWork &a, const SymWork &b) {
-        return (a.jt_end - a.jt_begin) > (b.jt_end - b.jt_begin);
+        return (long long)(a.jt_end - a.jt_begin) * a.s_count > (long long)(b.jt_end - b.jt_begin) * b.s_count;
     });
     const size_t el = s->is_f64 ? sizeof(double) : sizeof(float);
-    const size_t col_bytes = (size_t)c.dim * sp.np * el * (size_t)std::max(nrows, 1) * nsplit;
+    const size_t col_bytes = (size_t)c.dim * sp.np * el * (size_t)std::max(ncol, 1);
     if (col_bytes > (size_t)48 << 30) return NB_OK;       // fall back to the one-sided kernel
     sp.nwork = (int)work.size();
     sp.nslots = slots;
@@ -275,14 +292,16 @@ int build_sym_plan(nb_sim *s)
     HIPCHK(hipMalloc((void **)&sp.work, work.size() * sizeof(SymWork)));
     HIPCHK(hipMalloc((void **)&sp.row_slot0, sp.tiles * sizeof(int)));
     HIPCHK(hipMalloc((void **)&sp.row_nslots, sp.tiles * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&sp.row_ord, SR * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&sp.col_base, SR * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&sp.col_count, SR * sizeof(int)));
     HIPCHK(hipMalloc((void **)&sp.packed, (size_t)(c.dim + 1) * sp.np * el));
     HIPCHK(hipMalloc((void **)&sp.rowslab, (size_t)c.dim * sp.tile_b * sizeof(double) * (size_t)std::max(slots, 1)));
     HIPCHK(hipMalloc((void **)&sp.colslab, col_bytes));
     HIPCHK(hipMemcpy(sp.work, work.data(), work.size() * sizeof(SymWork), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(sp.row_slot0, slot0.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(sp.row_nslots, nslots.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp.row_ord, ord.data(), SR * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp.col_base, col_base.data(), SR * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp.col_count, col_count.data(), SR * sizeof(int), hipMemcpyHostToDevice));
     sp.enabled = true;
     return NB_OK;
 }
@@ -521,7 +540,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         // uniform-mass kernels leave out the mass factor: G*m in T arithmetic (fp32: (float)G * m)
         double scale = 1.0;
         if (sym_uniform) scale = s->is_f64 ? c.G * s->mass_value : (double)((float)c.G * (float)s->mass_value);
-        HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.row_ord, sp.nsplit,
+        HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.col_base, sp.col_count,
                                     sp.tile_b, c.n, sp.np, c.dim, s->is_f64, scale, s->acc, s->vel, half_dt, fuse_kick,
                                     s->stream));
     } else {
@@ -605,7 +624,7 @@ int nb_destroy(nb_sim *s)
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (void *p : {s->pos, s->vel, s->mass, s->acc, (void *)s->partial, s->staging, (void *)s->tab,
                     (void *)s->scratch, (void *)s->scalars, (void *)s->fbins, (void *)s->sym.work,
-                    (void *)s->sym.row_slot0, (void *)s->sym.row_nslots, (void *)s->sym.row_ord,
+                    (void *)s->sym.row_slot0, (void *)s->sym.row_nslots, (void *)s->sym.col_base, (void *)s->sym.col_count,
                     (void *)s->sym.packed, (void *)s->sym.rowslab, (void *)s->sym.colslab,
                     (void *)s->prune_cand, (void *)s->prune_rho, (void *)s->prune_state})
         if (p) (void)hipFree(p);

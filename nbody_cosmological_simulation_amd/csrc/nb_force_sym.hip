@@ -347,8 +347,8 @@ template <typename T, int D>
 __global__ void __launch_bounds__(NB_BLOCK)
 reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ colslab,
                   const int *__restrict__ row_slot0, const int *__restrict__ row_nslots,
-                  const int *__restrict__ row_ord, int nsplit, int tile_b, int n, int np, double scale,
-                  T *__restrict__ acc, T *__restrict__ vel, T half_dt, int do_kick)
+                  const int *__restrict__ col_base, const int *__restrict__ col_count, int tile_b, int n, int np,
+                  double scale, T *__restrict__ acc, T *__restrict__ vel, T half_dt, int do_kick)
 {
     __shared__ double s_part[NB_BLOCK / 64][D][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -373,12 +373,11 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
     const int nsr = SJ + (((J & 3) > 0) ? 1 : 0);
 #pragma unroll 4
     for (int SI = g; SI < nsr; SI += NB_BLOCK / 64) {
-        const int ord = row_ord[SI];
-        if (ord >= 0) {
-            for (int q = 0; q < nsplit; ++q)
+        // col_count = 0: super-row owned by another rank; > 1: its sweeps were cut into pieces
+        const int base = col_base[SI], cnt = col_count[SI];
+        for (int q = 0; q < cnt; ++q)
 #pragma unroll
-                for (int k = 0; k < D; ++k) s[k] += (double)colslab[((size_t)(ord * nsplit + q) * D + k) * np + pc];
-        }
+            for (int k = 0; k < D; ++k) s[k] += (double)colslab[((size_t)(base + q) * D + k) * np + pc];
     }
 #pragma unroll
     for (int k = 0; k < D; ++k) s_part[g][k][lane] = s[k];
@@ -580,14 +579,14 @@ hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int 
 }
 
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
-                                const int *row_nslots, const int *row_ord, int nsplit, int tile_b, int n, int np,
-                                int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
+                                const int *row_nslots, const int *col_base, const int *col_count, int tile_b, int n,
+                                int np, int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
                                 int do_kick, hipStream_t st)
 {
     const int grid = (n + 63) / 64;
 #define NB_RED(TT, DD) \
     hipLaunchKernelGGL((reduce_sym_kernel<TT, DD>), dim3(grid), dim3(NB_BLOCK), 0, st, rowslab, (const TT *)colslab, \
-                       row_slot0, row_nslots, row_ord, nsplit, tile_b, n, np, scale, (TT *)acc, (TT *)vel, (TT)half_dt, do_kick)
+                       row_slot0, row_nslots, col_base, col_count, tile_b, n, np, scale, (TT *)acc, (TT *)vel, (TT)half_dt, do_kick)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64) { if (dim == 2) NB_RED(double, 2); else NB_RED(double, 3); }
     else        { if (dim == 2) NB_RED(float, 2); else NB_RED(float, 3); }

@@ -57,7 +57,7 @@ struct SymWork {
     int jt_begin, jt_end;
     int slot;          // row-slab slot of wave 0 for this chunk; wave w uses slot + w * slot_stride
     int slot_stride;   // = number of (chunk, split) work items of this super-row
-    int col_ord;       // column-slab index: (ordinal of the owned super-row) * nsplit + split
+    int col_ord;       // column-slab index of this (super-row, split)
     int s_begin;       // first rotation step of this work item (0 unless the sweep is split)
     int s_count;       // rotation steps to run (64 = a full tile-vs-tile sweep)
 };
@@ -76,8 +76,8 @@ hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int 
                                    int r, int is_f64, int f32_terms, int mass_f32, double eps2, hipStream_t st);
 hipError_t nb_launch_final_sum(const double *part, int count, double *out, hipStream_t st);
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
-                                const int *row_nslots, const int *row_ord, int nsplit, int tile_b, int n, int np,
-                                int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
+                                const int *row_nslots, const int *col_base, const int *col_count, int tile_b, int n,
+                                int np, int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
                                 int do_kick, hipStream_t st);
 
 // ---- kernel launchers (implemented in the .hip files) --------------------------------------
