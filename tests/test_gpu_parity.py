@@ -207,6 +207,21 @@ def test_n65536_fp64_forces_and_invariants(nb):
     pe = sim.get_potential_energy()
     pe_ref = O.potential_energy_f64_fast(pos.numpy(), mass.numpy())
     assert abs(pe - pe_ref) <= 1e-12 * abs(pe_ref)
+    # 10 leapfrog steps against the oracle's fp64 step (BASELINE config 2 size; ~15 s of host time)
+    o = O.lib()
+    p64 = np.ascontiguousarray(pos.numpy()); v64 = np.ascontiguousarray(vel.numpy()); m64 = np.ascontiguousarray(mass.numpy())
+    a64 = O.accelerations_f64_fast(p64, m64)
+    o.nbo_step_f64_fast(n, 2, O._dp(p64), O._dp(v64), O._dp(m64), O._dp(a64), 0.001, 0.1 ** 2, 0.01, 10)
+    sim10 = nb.GalaxySimulation(pos, vel, mass, precision_mode=nb.PrecisionMode.FLOAT64)
+    e_start = sim10.get_total_energy()
+    sim10.run(10)
+    assert relerr(sim10.positions.numpy(), p64) < 1e-12
+    assert relerr(sim10.velocities.numpy(), v64) < 1e-11
+    ke_ref = 0.5 * float((m64 * (v64 ** 2).sum(1)).sum())
+    pe_ref10 = O.potential_energy_f64_fast(p64, m64)
+    drift_ref = (ke_ref + pe_ref10 - e_start) / abs(e_start)
+    drift = (sim10.get_total_energy() - e_start) / abs(e_start)
+    assert abs(drift - drift_ref) < 1e-10                      # north_star: energy drift matches to 1e-10
     # time reversal: run 5 steps, flip velocities, run 5 steps -> back to the start (leapfrog is reversible)
     e0 = sim.get_total_energy()
     sim.run(5)
