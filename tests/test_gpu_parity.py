@@ -209,7 +209,7 @@ def test_n65536_fp64_forces_and_invariants(nb):
     assert abs(pe - pe_ref) <= 1e-12 * abs(pe_ref)
     # 10 leapfrog steps against the oracle's fp64 step (BASELINE config 2 size; ~15 s of host time)
     o = O.lib()
-    p64 = np.ascontiguousarray(pos.numpy()); v64 = np.ascontiguousarray(vel.numpy()); m64 = np.ascontiguousarray(mass.numpy())
+    p64, v64, m64 = pos.numpy().copy(), vel.numpy().copy(), mass.numpy().copy()   # the oracle steps in place
     a64 = O.accelerations_f64_fast(p64, m64)
     o.nbo_step_f64_fast(n, 2, O._dp(p64), O._dp(v64), O._dp(m64), O._dp(a64), 0.001, 0.1 ** 2, 0.01, 10)
     sim10 = nb.GalaxySimulation(pos, vel, mass, precision_mode=nb.PrecisionMode.FLOAT64)
