@@ -685,3 +685,61 @@ def test_split_sweeps_match_whole_sweeps(nb, monkeypatch, split):
             if flips:
                 continue
         assert relerr(s32.accelerations.numpy(), r32) < 2e-6, mode
+
+
+def test_c_client_of_the_cabi(nb, tmp_path):
+    """A plain-C program (no Python, no torch) drives the engine through include/nbody_amd.h; its
+    numbers must equal the Python mirror's on the same inputs and agree with the oracle."""
+    import subprocess
+    from oracle import oracle as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "nbody_cosmological_simulation_amd")
+    exe = str(tmp_path / "cabi_smoke")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cabi", "cabi_smoke.c"),
+                           "-o", exe, "-L", pkg, "-lnbody_amd", f"-Wl,-rpath,{pkg}", "-lm"])
+    n, steps = 3000, 5
+    out = subprocess.run([exe, str(n), str(steps)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = [float(v) for v in out.stdout.split()]
+    # same LCG in numpy
+    s = np.uint64(12345)
+    vals = []
+    with np.errstate(over="ignore"):
+        for _ in range(5 * n):
+            s = s * np.uint64(6364136223846793005) + np.uint64(1442695040888963407)
+            vals.append(float((int(s) >> 11) & ((1 << 53) - 1)) / float(1 << 53))
+    v = np.array(vals).reshape(n, 5)
+    pos = np.stack([20 * v[:, 0] - 10, 20 * v[:, 1] - 10], 1)
+    vel = np.stack([0.2 * v[:, 2] - 0.1, 0.2 * v[:, 3] - 0.1], 1)
+    mass = 0.5 + v[:, 4]
+    sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode.FLOAT64)
+    sim.run(steps)
+    mine = [n, sim.get_kinetic_energy(), sim.get_potential_energy(), float(sim.positions.numpy().sum()),
+            float(sim.velocities.numpy().sum())]
+    assert got[0] == n
+    for a, b in zip(got[1:3], mine[1:3]):
+        assert a == b                       # same library, same inputs: identical bits
+    ref = O.OracleSim(pos, vel, mass, "float64")
+    ref.run(steps)
+    assert abs(got[1] - ref.get_kinetic_energy()) <= 1e-12 * abs(got[1])
+    assert abs(got[2] - ref.get_potential_energy()) <= 1e-12 * abs(got[2])
+
+
+def test_integration_md_ctypes_stub_runs(nb):
+    """The minimal ctypes stub printed in INTEGRATION.md section 3 is executable as written."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "class GalaxySimulation" in b][0]
+    stub = stub.replace('C.CDLL("libnbody_amd.so")', f'C.CDLL("{nb._native.LIB_PATH}")')
+    ns = {}
+    exec(stub, ns)
+    g = load_golden("g1_n257_d2_e0.05.npz")
+    s = ns["GalaxySimulation"](T(g["pos"]), T(g["vel"]), T(g["mass"]), nb.PrecisionMode.FLOAT64, softening=0.05)
+    s.step()
+    pos = torch.empty(257, 2, dtype=torch.float64)
+    vel = torch.empty(257, 2, dtype=torch.float64)
+    s.read(pos, vel)
+    assert relerr(pos.numpy(), g["float64/pos1"]) < 1e-13
+    assert np.isfinite(s.get_total_energy())
