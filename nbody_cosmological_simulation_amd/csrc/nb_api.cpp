@@ -138,7 +138,7 @@ struct nb_sim {
     // pair-symmetric fp64 path (nb_force_sym.hip)
     struct SymPlan {
         bool enabled = false;
-        int r = 2, tile_b = 128, tiles = 0, np = 0, nwork = 0, nslots = 0, nrows = 0, nsplit = 1;
+        int r = 2, tile_b = 128, tiles = 0, np = 0, nwork = 0, nslots = 0;
         SymWork *work = nullptr;
         int *row_slot0 = nullptr, *row_nslots = nullptr, *col_base = nullptr, *col_count = nullptr;
         void *packed = nullptr, *colslab = nullptr;   // storage type of the state (fp32 or fp64)
@@ -257,7 +257,6 @@ int build_sym_plan(nb_sim *s)
                 if (ord[S] >= 0) { split_of[S] = 4; rem -= nch_of[S]; }
         }
     }
-    sp.nsplit = 1;
     std::vector<SymWork> work;
     std::vector<int> col_base(SR, 0), col_count(SR, 0);
     int slots = 0, ncol = 0;
@@ -287,7 +286,6 @@ int build_sym_plan(nb_sim *s)
     if (col_bytes > (size_t)48 << 30) return NB_OK;       // fall back to the one-sided kernel
     sp.nwork = (int)work.size();
     sp.nslots = slots;
-    sp.nrows = nrows;
     if (sp.nwork == 0) return NB_OK;
     HIPCHK(hipMalloc((void **)&sp.work, work.size() * sizeof(SymWork)));
     HIPCHK(hipMalloc((void **)&sp.row_slot0, sp.tiles * sizeof(int)));

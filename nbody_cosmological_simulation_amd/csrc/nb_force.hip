@@ -15,11 +15,13 @@
 //   inner loop is written for minimum instruction count: one v_rsq + a fused second-order
 //   correction instead of sqrt/div/pow, no self-interaction mask (d == 0 kills the diagonal
 //   term exactly as the reference's (1 - eye) multiply does, NaN cases included).
-#include "nb_internal.h"
+#include "nb_device.h"
 
 #include <hip/hip_fp16.h>
 
 namespace {
+
+using namespace nbdev;
 
 // ------------------------------------------------------------------------------------------
 // q^(-3/2) kernels
@@ -49,30 +51,6 @@ __device__ __forceinline__ float inv_r3_f32(float q)
     const float e = __builtin_fmaf(-t, y0, 1.0f);
     const float y = __builtin_fmaf(0.5f * y0, e, y0);
     return (y * y) * y;
-}
-
-__device__ __forceinline__ float round_bf16(float x) { return (float)(__bf16)x; }
-__device__ __forceinline__ float round_f16(float x) { return (float)(_Float16)x; }
-
-// r2 exactly as the reference's fp32 tensors produce it: (dx*dx + dy*dy [+ dz*dz]) + eps2, one
-// rounding per operation, no fused multiply-add (simulation.py:86).
-template <int D>
-__device__ __forceinline__ float r2_f32_exact(const float *d, float eps2)
-{
-    float s = __fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1]));
-    if (D == 3) s = __fadd_rn(s, __fmul_rn(d[2], d[2]));
-    return __fadd_rn(s, eps2);
-}
-
-// bin index = number of thresholds <= r2 (branch-free binary search over the LDS table)
-template <int LP>
-__device__ __forceinline__ int grid_bin_lookup(const float *thr, float r2)
-{
-    int k = 0;
-#pragma unroll
-    for (int step = LP / 2; step >= 1; step >>= 1)
-        k += (thr[k + step] <= r2) ? step : 0;
-    return k;
 }
 
 // ------------------------------------------------------------------------------------------

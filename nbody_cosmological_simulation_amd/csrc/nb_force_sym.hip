@@ -20,11 +20,13 @@
 //   LDS in a fixed order, so one column slab per super-row leaves the chip (4x less slab traffic
 //   than one per row).  Row sums go to per-(row, chunk) slots.  reduce_sym_kernel adds slots and
 //   slabs in a fixed order: no atomics, run-to-run bit-identical.
-#include "nb_internal.h"
+#include "nb_device.h"
 
 #include <type_traits>
 
 namespace {
+
+using namespace nbdev;
 
 template <typename T>
 __device__ __forceinline__ T rot1(T v, int addr);
@@ -73,32 +75,6 @@ __device__ __forceinline__ float inv_r3_sym(float q, float c15, float)
     return __builtin_fmaf(ve, c15, v);
 }
 
-template <int LP>
-__device__ __forceinline__ int grid_bin_lookup(const float *thr, float r2)
-{
-    int k = 0;
-#pragma unroll
-    for (int step = LP / 2; step >= 1; step >>= 1)
-        k += (thr[k + step] <= r2) ? step : 0;
-    return k;
-}
-
-// Exact bin from an estimate: k0 = rint(log2(r2)*a + b) is within one bin of the true index
-// (grid_tables_kernel guarantees it when tab->use_est), thr[k0] / thr[k0+1] settle it.
-__device__ __forceinline__ int grid_bin_estimate(const float *thr, float r2, float est_a, float est_b, int lmax_bin)
-{
-    const float ne = __builtin_fmaf(__builtin_amdgcn_logf(r2), est_a, est_b);
-    int k0 = (int)(ne + 0.5f);
-    k0 = min(max(k0, 0), lmax_bin);
-    const float lo = thr[k0], hi = thr[k0 + 1];
-    return k0 - ((r2 < lo) ? 1 : 0) + ((r2 >= hi) ? 1 : 0);
-}
-
-// One tile-vs-tile sweep: 64 steps, R*R pairs per lane per step, J data rotating by one lane.
-// DIAG:    J is the target tile itself -> one-sided (each ordered pair once, mirrors dropped).
-// UNIFORM: all masses equal -> the mass factor is applied once to the finished sums
-//          (reduce_sym_kernel), saving both mass multiplies and the rotation of the masses.
-// HOOK:    precision hook applied to the fp32 r2 (HOOK_NONE for fp64).
 struct GridArgs {
     const float *thr, *lut;
     float est_a, est_b, gfac;
@@ -106,6 +82,12 @@ struct GridArgs {
     bool degenerate;
 };
 
+// One tile-vs-tile sweep: `nsteps` rotation steps (64 = the whole tile pair), R*R pairs per lane per
+// step, J data rotating by one lane per step.
+// DIAG:    J is the target tile itself -> one-sided (each ordered pair once, mirrors dropped).
+// UNIFORM: all masses equal -> the mass factor is applied once to the finished sums
+//          (reduce_sym_kernel), saving both mass multiplies and the rotation of the masses.
+// HOOK:    precision hook applied to the fp32 r2 (HOOK_NONE for fp64); EST: grid bins by estimate.
 template <typename T, int D, int R, bool DIAG, bool UNIFORM, int HOOK, bool EST>
 __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (&ai)[R][D], T (&xj)[R][D],
                                       T (&gj)[R], T (&aj)[R][D], T eps2, int rot_addr, const GridArgs &ga,

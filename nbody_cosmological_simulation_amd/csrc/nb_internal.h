@@ -23,12 +23,9 @@ struct GridTables {
     float r2max;             // max over all pairs of fp32 r2
     float est_a, est_b;      // bin estimate: rint(log2(r2)*est_a + est_b) is within +-1 of the exact bin
     int use_est;             // 1: the estimate is safe (est_a small enough for v_log_f32's error)
-    float fmin, fmax;        // linear force grid bounds (quantization.py:78-79)
     int degenerate;          // 1: lmax-lmin < 1e-10 -> values pass through clamped
-    int fdegenerate;         // 1: fmax-fmin < 1e-10 -> forces pass through
     int levels;
     unsigned int r2max_bits; // atomicMax target (positive floats order as unsigned ints)
-    unsigned int fmin_bits, fmax_bits;
 };
 
 // Scratch of the pruned max-r2 search (nb_force.hip "K2 with pruning").

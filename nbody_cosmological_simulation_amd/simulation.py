@@ -20,6 +20,7 @@ Subclass rule: `__init__` and `step` dispatch through
 natively; otherwise the whole step is one native call.
 """
 import ctypes as C
+import os
 from typing import Callable
 
 import torch
@@ -70,7 +71,6 @@ class GalaxySimulation:
         self._native_acc = None
         rank, world = runtime.rank_world()
         flags = N.NB_FLAG_PROFILE if profile else 0
-        import os
         fake = os.environ.get("NBODY_SHARD_TIMING")       # "r/P": time one shard of P on a single GPU
         if fake and shard is None and runtime.force_comm():
             rank, world = (int(v) for v in fake.split("/"))
