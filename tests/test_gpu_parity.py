@@ -743,3 +743,27 @@ def test_integration_md_ctypes_stub_runs(nb):
     s.read(pos, vel)
     assert relerr(pos.numpy(), g["float64/pos1"]) < 1e-13
     assert np.isfinite(s.get_total_energy())
+
+
+def test_2000_tick_horizon_fp64_vs_oracle(nb):
+    """BASELINE config 2 horizon (2 000 ticks) at the reference-runnable size N = 1024: trajectory and
+    energy drift against the oracle (pinned to the reference up to 200 ticks by the golden vectors;
+    the reference's own self-noise at 2 000 ticks is 3.7e-12 of the system scale)."""
+    from oracle import oracle as O
+    g = load_golden("g2_config1_n1024.npz")
+    sim = mk(nb, g, "float64")
+    ref = O.OracleSim(g["pos"], g["vel"], g["mass"], "float64")
+    e0 = sim.get_total_energy()
+    ref.step()                                   # fp32-typed first step: generic oracle
+    p, v, m, a = (np.ascontiguousarray(x, np.float64).copy() for x in
+                  (ref.positions, ref.velocities, ref.masses, ref.accelerations))
+    O.lib().nbo_step_f64_fast(1024, 2, O._dp(p), O._dp(v), O._dp(m), O._dp(a), 0.001, 0.1 ** 2, 0.01, 1999)
+    sim.run(2000)
+    scale = np.abs(p).max()
+    err = np.abs(sim.positions.numpy() - p).max() / scale
+    verr = np.abs(sim.velocities.numpy() - v).max() / np.abs(v).max()
+    e_ref = 0.5 * float((m * (v ** 2).sum(1)).sum()) + O.potential_energy_f64_fast(p, m)
+    drift, drift_ref = (sim.get_total_energy() - e0) / abs(e0), (e_ref - e0) / abs(e0)
+    print(f"2000 ticks: pos err {err:.2e} vel err {verr:.2e} drift {drift:.6e} (oracle {drift_ref:.6e})")
+    assert err < 1e-10 and verr < 1e-9
+    assert abs(drift - drift_ref) < 1e-10
