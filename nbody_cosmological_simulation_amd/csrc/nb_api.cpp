@@ -327,13 +327,16 @@ int ensure_storage(nb_sim *s, bool f64)
     const size_t pe_blocks = (size_t)((s->cfg.n + NB_BLOCK - 1) / NB_BLOCK) * s->geom.nchunks;
     s->scratch_elems = std::max<size_t>(pe_blocks, 1024);
     HIPCHK(hipMalloc((void **)&s->scratch, s->scratch_elems * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&s->scalars, 8 * sizeof(double)));
-    HIPCHK(hipMemsetAsync(s->scalars, 0, 8 * sizeof(double), s->stream));
+    // scalars[0..7] results, [8 ...] partials of the two-stage min/max
+    HIPCHK(hipMalloc((void **)&s->scalars, (8 + 2 * NB_MINMAX_BLOCKS) * sizeof(double)));
+    HIPCHK(hipMemsetAsync(s->scalars, 0, (8 + 2 * NB_MINMAX_BLOCKS) * sizeof(double), s->stream));
     if (force_quant_mode(s->cfg)) HIPCHK(hipMalloc((void **)&s->fbins, cnt * sizeof(int16_t)));
     if (!f64 && grid_mode(s->cfg.mode)) {
         HIPCHK(hipMalloc((void **)&s->prune_cand, cnt * sizeof(float)));
         HIPCHK(hipMalloc((void **)&s->prune_rho, (size_t)s->cfg.n * sizeof(float)));
         HIPCHK(hipMalloc((void **)&s->prune_state, sizeof(PruneState)));
+        const PruneState init = {{0xffffffffu, 0xffffffffu, 0xffffffffu}, {0u, 0u, 0u}, 0ull, {0ull, 0ull}, 0, 0};
+        HIPCHK(hipMemcpy(s->prune_state, &init, sizeof init, hipMemcpyHostToDevice));
     }
     HIPCHK(hipMemsetAsync(s->acc, 0, cnt * el, s->stream));
     if (int rc = build_sym_plan(s)) return rc;
@@ -354,7 +357,9 @@ int upload(nb_sim *s, const void *src, int dt, int on_device, void *dst, int64_t
     if (dt == sdt) {
         HIPCHK(hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                               s->stream));
-        if (!on_device) HIPCHK(hipStreamSynchronize(s->stream));   // caller may reuse its buffer
+        // the caller owns `src` and may free or overwrite it as soon as we return (a torch temporary
+        // goes back to the caching allocator): the copy must have consumed it by then
+        HIPCHK(hipStreamSynchronize(s->stream));
         return NB_OK;
     }
     const void *dsrc = src;
@@ -364,6 +369,7 @@ int upload(nb_sim *s, const void *src, int dt, int on_device, void *dst, int64_t
         dsrc = s->staging;
     }
     HIPCHK(nb_launch_convert(dsrc, dt, dst, sdt, count, s->stream));
+    if (on_device) HIPCHK(hipStreamSynchronize(s->stream));        // same ownership rule as above
     return NB_OK;
 }
 
@@ -506,7 +512,8 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
                     NCCLCHK(g_rccl.AllReduce(&s->tab->r2max_bits, &s->tab->r2max_bits, 1, ncclUint32, ncclMax, s->comm,
                                              s->stream));
             }
-            HIPCHK(nb_launch_grid_tables(s->tab, L, (float)c.G, eps2, 0.01f, s->stream));
+            HIPCHK(nb_launch_grid_tables(s->tab, L, (float)c.G, eps2, 0.01f,
+                                         getenv("NB_NO_PRUNE") ? nullptr : s->prune_state, s->stream));
         }
         used_sym = s->sym.enabled && pa == NB_F32;
         if (used_sym) {
@@ -549,7 +556,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         NCCLCHK(g_rccl.AllReduce(s->acc, s->acc, (size_t)cnt, s->is_f64 ? ncclDouble : ncclFloat, ncclSum, s->comm,
                                  s->stream));
     if (fq) {
-        HIPCHK(nb_launch_minmax_generic(s->acc, 0, cnt, 0, 0.0, s->scalars, s->stream));
+        HIPCHK(nb_launch_minmax_generic(s->acc, 0, cnt, 0, 0.0, s->scalars, s->scalars + 8, s->stream));
         HIPCHK(nb_launch_force_quant_bins((const float *)s->acc, (float *)s->acc, cnt, mode_levels(c), s->scalars,
                                           s->fbins, s->stream));
     }
@@ -664,7 +671,7 @@ int nb_set_state(nb_sim *s, const void *pos, const void *vel, const void *mass, 
         s->have_mass = true;
         // uniform-mass detection (one min/max pass on the device per upload, not per step)
         double mm[2];
-        HIPCHK(nb_launch_minmax_generic(s->mass, s->is_f64, s->cfg.n, 0, 0.0, s->scalars + 4, s->stream));
+        HIPCHK(nb_launch_minmax_generic(s->mass, s->is_f64, s->cfg.n, 0, 0.0, s->scalars + 4, s->scalars + 8, s->stream));
         HIPCHK(hipMemcpyAsync(mm, s->scalars + 4, sizeof mm, hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
         s->mass_uniform = (mm[0] == mm[1]) && std::isfinite(mm[0]) && !getenv("NB_NO_UNIFORM");
@@ -866,7 +873,7 @@ int with_device_buffers(int device, const void *in, void *out, size_t in_bytes, 
     if (device < 0 || device >= ndev) return fail(NB_ERR_NO_DEVICE, "device %d out of range", device);
     DeviceGuard guard(device);
     TempBuf tin, tout, tscal;
-    HIPCHK(hipMalloc(&tscal.p, 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&tscal.p, (2 + 2 * NB_MINMAX_BLOCKS) * sizeof(double)));
     const void *din = in;
     void *dout = out;
     if (!on_device) {
@@ -891,7 +898,7 @@ int nb_grid_quantize(int device, const void *in, void *out, int64_t count, int d
     if (count < 1 || levels < 2) return fail(NB_ERR_INVALID, "count >= 1 and levels >= 2 required");
     const size_t bytes = (size_t)count * dt_size(dtype);
     return with_device_buffers(device, in, out, bytes, bytes, on_device, [&](const void *din, void *dout, double *sc) {
-        HIPCHK(nb_launch_minmax_generic(din, dtype == NB_F64, count, 0, 0.0, sc, nullptr));
+        HIPCHK(nb_launch_minmax_generic(din, dtype == NB_F64, count, 0, 0.0, sc, sc + 2, nullptr));
         HIPCHK(nb_launch_grid_quantize(din, dout, dtype == NB_F64, count, levels, sc, nullptr));
         return (int)NB_OK;
     });
@@ -904,7 +911,7 @@ int nb_grid_quantize_safe(int device, const void *in, void *out, int64_t count, 
     if (count < 1 || levels < 2) return fail(NB_ERR_INVALID, "count >= 1 and levels >= 2 required");
     const size_t bytes = (size_t)count * dt_size(dtype);
     return with_device_buffers(device, in, out, bytes, bytes, on_device, [&](const void *din, void *dout, double *sc) {
-        HIPCHK(nb_launch_minmax_generic(din, dtype == NB_F64, count, 1, min_val, sc, nullptr));
+        HIPCHK(nb_launch_minmax_generic(din, dtype == NB_F64, count, 1, min_val, sc, sc + 2, nullptr));
         HIPCHK(nb_launch_grid_quantize_safe(din, dout, dtype == NB_F64, count, levels, min_val, sc, nullptr));
         return (int)NB_OK;
     });

@@ -373,44 +373,59 @@ r2max_kernel(const float *__restrict__ pos, ForceGeom g, float eps2, GridTables 
 // Candidates passing that test are compacted and scanned exhaustively with the exact r2 formula.
 // For a disk galaxy this keeps a few percent of the particles (~0.1 % of the pairs).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
-prune_bbox_kernel(const float *__restrict__ pos, int n, int dim, PruneState *__restrict__ ps)
+// Stage 1 of the bounding box: per-block min/max of every coordinate (+ a NaN flag) as ordered
+// integer keys folded with atomics; the rho kernel decodes them (two launches, a few us each).
+__device__ __forceinline__ unsigned int order_key(float v)
 {
-    __shared__ float s_mn[3][16], s_mx[3][16];
+    const unsigned int u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // monotone in v for all finite values
+}
+__device__ __forceinline__ float order_unkey(unsigned int k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+template <int D>
+__global__ void __launch_bounds__(NB_BLOCK)
+prune_bbox_kernel(const float *__restrict__ pos, int n, PruneState *__restrict__ ps)
+{
+    __shared__ unsigned int s_mn[D][NB_BLOCK / 64], s_mx[D][NB_BLOCK / 64];
     __shared__ int s_nan;
     if (threadIdx.x == 0) s_nan = 0;
     __syncthreads();
-    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
-    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    unsigned int mn[D], mx[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { mn[k] = 0xffffffffu; mx[k] = 0u; }
     bool bad = false;
-    for (int i = threadIdx.x; i < n; i += 1024)
-        for (int k = 0; k < dim; ++k) {
-            const float v = pos[(size_t)i * dim + k];
+    for (int i = blockIdx.x * NB_BLOCK + threadIdx.x; i < n; i += gridDim.x * NB_BLOCK)
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const float v = pos[(size_t)i * D + k];
             bad |= (v != v);
-            mn[k] = fminf(mn[k], v);
-            mx[k] = fmaxf(mx[k], v);
+            const unsigned int key = order_key(v);
+            mn[k] = min(mn[k], key);
+            mx[k] = max(mx[k], key);
         }
     if (bad) s_nan = 1;
-    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
-            mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64));
-            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
+            mn[k] = min(mn[k], (unsigned int)__shfl_xor((int)mn[k], off, 64));
+            mx[k] = max(mx[k], (unsigned int)__shfl_xor((int)mx[k], off, 64));
         }
         if ((threadIdx.x & 63) == 0) { s_mn[k][threadIdx.x >> 6] = mn[k]; s_mx[k][threadIdx.x >> 6] = mx[k]; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 0; k < 3; ++k) {
-            float a = s_mn[k][0], b = s_mx[k][0];
-            for (int w = 1; w < 16; ++w) { a = fminf(a, s_mn[k][w]); b = fmaxf(b, s_mx[k][w]); }
-            ps->center[k] = (k < dim) ? 0.5f * a + 0.5f * b : 0.0f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            unsigned int a = s_mn[k][0], b = s_mx[k][0];
+            for (int w = 1; w < NB_BLOCK / 64; ++w) { a = min(a, s_mn[k][w]); b = max(b, s_mx[k][w]); }
+            atomicMin(&ps->box_min[k], a);
+            atomicMax(&ps->box_max[k], b);
         }
-        ps->far = 0ull;
-        ps->lb[0] = 0ull;
-        ps->lb[1] = 0ull;
-        ps->count = 0;
-        ps->nan_flag = s_nan;
+        if (s_nan) atomicOr(&ps->nan_flag, 1);
     }
 }
 
@@ -424,6 +439,21 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
+// one atomic per block instead of one per wave
+__device__ __forceinline__ void block_atomic_max_u64(unsigned long long key, unsigned long long *dst)
+{
+    __shared__ unsigned long long s_key[NB_BLOCK / 64];
+    key = wave_max_u64(key);
+    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = s_key[0];
+#pragma unroll
+        for (int w = 1; w < NB_BLOCK / 64; ++w) m = s_key[w] > m ? s_key[w] : m;
+        if (m) atomicMax(dst, m);
+    }
+}
+
 template <int D>
 __global__ void __launch_bounds__(NB_BLOCK)
 prune_rho_kernel(const float *__restrict__ pos, int n, float *__restrict__ rho, PruneState *__restrict__ ps)
@@ -434,15 +464,15 @@ prune_rho_kernel(const float *__restrict__ pos, int n, float *__restrict__ rho, 
         float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            const float d = pos[(size_t)i * D + k] - ps->center[k];
+            const float c = 0.5f * order_unkey(ps->box_min[k]) + 0.5f * order_unkey(ps->box_max[k]);
+            const float d = pos[(size_t)i * D + k] - c;
             s += d * d;
         }
         const float r = sqrtf(s);
         rho[i] = r;
         key = ((unsigned long long)__float_as_uint(r) << 32) | (unsigned int)i;
     }
-    key = wave_max_u64(key);
-    if ((threadIdx.x & 63) == 0 && key) atomicMax(&ps->far, key);
+    block_atomic_max_u64(key, &ps->far);
 }
 
 // farthest partner (by the exact fp32 r2) of the particle whose index is stored in *src_key
@@ -460,8 +490,7 @@ prune_hop_kernel(const float *__restrict__ pos, int n, float eps2, const unsigne
         for (int k = 0; k < D; ++k) d[k] = __fsub_rn(pos[(size_t)j * D + k], pos[(size_t)f * D + k]);
         key = ((unsigned long long)r2_order_bits(r2_f32_exact<D>(d, eps2)) << 32) | (unsigned int)j;
     }
-    key = wave_max_u64(key);
-    if ((threadIdx.x & 63) == 0 && key) atomicMax(dst_key, key);
+    block_atomic_max_u64(key, dst_key);
 }
 
 template <int D>
@@ -549,7 +578,8 @@ __device__ __forceinline__ float grid_bin_exact(float t, float min_val, float lm
 }
 
 __global__ void __launch_bounds__(NB_MAX_LUT)
-grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2, float min_val)
+grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2, float min_val,
+                   PruneState *__restrict__ ps)
 {
     const int k = threadIdx.x;
     const float r2max = __uint_as_float(tab->r2max_bits);
@@ -588,6 +618,15 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
             }
         }
         tab->thr[k] = thr;
+    }
+    if (k == 0 && ps) {
+        // the pruned max-r2 search is finished: reset its scratch for the next evaluation
+        for (int c = 0; c < 3; ++c) { ps->box_min[c] = 0xffffffffu; ps->box_max[c] = 0u; }
+        ps->far = 0ull;
+        ps->lb[0] = 0ull;
+        ps->lb[1] = 0ull;
+        ps->count = 0;
+        ps->nan_flag = 0;
     }
     if (k == 0) {
         // sentinel above the last bin: NaN compares false, so a lookup can never step past L-1
@@ -718,9 +757,12 @@ hipError_t nb_launch_r2max_pruned(const float *pos, int n, int dim, float eps2, 
                                   PruneState *ps, GridTables *tab, hipStream_t st)
 {
     const int blocks = (n + NB_BLOCK - 1) / NB_BLOCK;
-    hipLaunchKernelGGL(prune_bbox_kernel, dim3(1), dim3(1024), 0, st, pos, n, dim, ps);
+    const int bbox_blocks = blocks < 128 ? blocks : 128;
+    // *ps is in its reset state on entry: nb_api.cpp initialises it once, grid_tables_kernel (which
+    // always follows) puts it back after use -- no per-step memset / copy launches
     return dispatch_dim(dim, [&](auto D) {
         constexpr int DD = decltype(D)::value;
+        hipLaunchKernelGGL((prune_bbox_kernel<DD>), dim3(bbox_blocks), dim3(NB_BLOCK), 0, st, pos, n, ps);
         hipLaunchKernelGGL((prune_rho_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, pos, n, rho, ps);
         hipLaunchKernelGGL((prune_hop_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, pos, n, eps2, &ps->far, &ps->lb[0]);
         hipLaunchKernelGGL((prune_hop_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, pos, n, eps2, &ps->lb[0], &ps->lb[1]);
@@ -730,9 +772,10 @@ hipError_t nb_launch_r2max_pruned(const float *pos, int n, int dim, float eps2, 
     });
 }
 
-hipError_t nb_launch_grid_tables(GridTables *tab, int levels, float G, float eps2, float min_val, hipStream_t st)
+hipError_t nb_launch_grid_tables(GridTables *tab, int levels, float G, float eps2, float min_val, PruneState *ps,
+                                 hipStream_t st)
 {
-    hipLaunchKernelGGL(grid_tables_kernel, dim3(1), dim3(NB_MAX_LUT), 0, st, tab, levels, G, eps2, min_val);
+    hipLaunchKernelGGL(grid_tables_kernel, dim3(1), dim3(NB_MAX_LUT), 0, st, tab, levels, G, eps2, min_val, ps);
     return hipGetLastError();
 }
 

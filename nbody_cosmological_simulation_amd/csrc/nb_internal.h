@@ -30,8 +30,9 @@ struct GridTables {
 
 // Scratch of the pruned max-r2 search (nb_force.hip "K2 with pruning").
 struct PruneState {
-    float center[3];          // bounding-box centre
-    unsigned long long far;   // (rho bits << 32 | index) of the particle farthest from the centre
+    unsigned int box_min[3];  // ordered-integer keys of the coordinate minima / maxima (bounding box)
+    unsigned int box_max[3];
+    unsigned long long far;   // (rho bits << 32 | index) of the particle farthest from the box centre
     unsigned long long lb[2]; // (r2 bits << 32 | index): farthest partner of `far`, then of that partner
     int count;                // candidates kept
     int nan_flag;             // a NaN coordinate was seen -> r2max is NaN
@@ -95,7 +96,7 @@ hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float 
 hipError_t nb_launch_r2max_pruned(const float *pos, int n, int dim, float eps2, float *cand, float *rho,
                                   PruneState *ps, GridTables *tab, hipStream_t st);
 hipError_t nb_launch_grid_tables(GridTables *tab, int levels, float G, float eps2, float min_val,
-                                 hipStream_t st);
+                                 PruneState *ps /* reset after use; may be null */, hipStream_t st);
 hipError_t nb_launch_d2bins(const float *pos, int n, int dim, float eps2, const GridTables *tab,
                             int16_t *bins, hipStream_t st);
 
@@ -119,8 +120,10 @@ hipError_t nb_launch_potential(const void *pos, const void *mass, const ForceGeo
 
 // tensor-level hooks (quantization.py module functions)
 hipError_t nb_launch_cast_hook(const void *in, int in_dt, void *out, int mode, int64_t count, hipStream_t st);
+// two-stage min/max; partials: device scratch of 2 * NB_MINMAX_BLOCKS doubles
+constexpr int NB_MINMAX_BLOCKS = 256;
 hipError_t nb_launch_minmax_generic(const void *in, int is_f64, int64_t count, int log_clamped, double min_val,
-                                    double *mn_mx /* device, 2 doubles */, hipStream_t st);
+                                    double *mn_mx /* device, 2 doubles */, double *partials, hipStream_t st);
 hipError_t nb_launch_grid_quantize(const void *in, void *out, int is_f64, int64_t count, int levels,
                                    const double *mn_mx, hipStream_t st);
 hipError_t nb_launch_grid_quantize_safe(const void *in, void *out, int is_f64, int64_t count, int levels,

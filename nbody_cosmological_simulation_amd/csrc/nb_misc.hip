@@ -104,14 +104,15 @@ template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int off);
 template <> __device__ __forceinline__ float shfl_xor_t<float>(float v, int off) { return __shfl_xor(v, off, 64); }
 template <> __device__ __forceinline__ double shfl_xor_t<double>(double v, int off) { return __shfl_xor(v, off, 64); }
 
-// single-block min/max over `count` elements (count = N*D <= a few million: microseconds)
+// min/max over `count` elements in two short stages (a single block needs ~40 us for 131 072
+// forces): stage 1 = up to MM_BLOCKS blocks write per-block partials, stage 2 = one block folds them.
+constexpr int MM_BLOCKS = 256;
+
 template <typename T, bool LOGC>
-__global__ void __launch_bounds__(1024)
-minmax_kernel(const T *__restrict__ in, int64_t count, T min_val, double *__restrict__ out)
+__device__ __forceinline__ void minmax_block(const T *__restrict__ in, int64_t begin, int64_t end, int64_t stride,
+                                             T min_val, T &mn, T &mx)
 {
-    __shared__ T s_mn[16], s_mx[16];
-    T mn = (T)__builtin_inf(), mx = -(T)__builtin_inf();
-    for (int64_t i = threadIdx.x; i < count; i += 1024) {
+    for (int64_t i = begin; i < end; i += stride) {
         T v = in[i];
         if (LOGC) {
             v = (v < min_val) ? min_val : v;
@@ -120,6 +121,11 @@ minmax_kernel(const T *__restrict__ in, int64_t count, T min_val, double *__rest
         mn = nan_min(mn, v);
         mx = nan_max(mx, v);
     }
+}
+
+template <typename T>
+__device__ __forceinline__ void minmax_fold(T &mn, T &mx, T *s_mn, T *s_mx)
+{
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         mn = nan_min(mn, shfl_xor_t<T>(mn, off));
@@ -127,11 +133,32 @@ minmax_kernel(const T *__restrict__ in, int64_t count, T min_val, double *__rest
     }
     if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) { mn = nan_min(mn, s_mn[w]); mx = nan_max(mx, s_mx[w]); }
-        out[0] = (double)mn;
-        out[1] = (double)mx;
+    if (threadIdx.x == 0)
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { mn = nan_min(mn, s_mn[w]); mx = nan_max(mx, s_mx[w]); }
+}
+
+template <typename T, bool LOGC>
+__global__ void __launch_bounds__(256)
+minmax_stage1_kernel(const T *__restrict__ in, int64_t count, T min_val, double *__restrict__ partials)
+{
+    __shared__ T s_mn[4], s_mx[4];
+    T mn = (T)__builtin_inf(), mx = -(T)__builtin_inf();
+    minmax_block<T, LOGC>(in, (int64_t)blockIdx.x * 256 + threadIdx.x, count, (int64_t)gridDim.x * 256, min_val, mn, mx);
+    minmax_fold<T>(mn, mx, s_mn, s_mx);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = (double)mn; partials[2 * blockIdx.x + 1] = (double)mx; }
+}
+
+__global__ void __launch_bounds__(256)
+minmax_stage2_kernel(const double *__restrict__ partials, int nblocks, double *__restrict__ out)
+{
+    __shared__ double s_mn[4], s_mx[4];
+    double mn = __builtin_inf(), mx = -__builtin_inf();
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        mn = nan_min(mn, partials[2 * i]);
+        mx = nan_max(mx, partials[2 * i + 1]);
     }
+    minmax_fold<double>(mn, mx, s_mn, s_mx);
+    if (threadIdx.x == 0) { out[0] = mn; out[1] = mx; }
 }
 
 // quantization.py:74-88 elementwise part, T arithmetic, one rounding per op
@@ -411,19 +438,16 @@ hipError_t nb_launch_convert(const void *in, int in_dt, void *out, int out_dt, i
 }
 
 hipError_t nb_launch_minmax_generic(const void *in, int is_f64, int64_t count, int log_clamped, double min_val,
-                                    double *mn_mx, hipStream_t st)
+                                    double *mn_mx, double *partials, hipStream_t st)
 {
-    if (is_f64) {
-        if (log_clamped)
-            hipLaunchKernelGGL((minmax_kernel<double, true>), dim3(1), dim3(1024), 0, st, (const double *)in, count, min_val, mn_mx);
-        else
-            hipLaunchKernelGGL((minmax_kernel<double, false>), dim3(1), dim3(1024), 0, st, (const double *)in, count, min_val, mn_mx);
-    } else {
-        if (log_clamped)
-            hipLaunchKernelGGL((minmax_kernel<float, true>), dim3(1), dim3(1024), 0, st, (const float *)in, count, (float)min_val, mn_mx);
-        else
-            hipLaunchKernelGGL((minmax_kernel<float, false>), dim3(1), dim3(1024), 0, st, (const float *)in, count, (float)min_val, mn_mx);
-    }
+    int blocks = (int)((count + 1023) / 1024);          // >= 4 elements per thread
+    blocks = blocks < 1 ? 1 : (blocks > MM_BLOCKS ? MM_BLOCKS : blocks);
+#define NB_MM(TT, LL) \
+    hipLaunchKernelGGL((minmax_stage1_kernel<TT, LL>), dim3(blocks), dim3(256), 0, st, (const TT *)in, count, (TT)min_val, partials)
+    if (is_f64) { if (log_clamped) NB_MM(double, true); else NB_MM(double, false); }
+    else        { if (log_clamped) NB_MM(float, true); else NB_MM(float, false); }
+#undef NB_MM
+    hipLaunchKernelGGL(minmax_stage2_kernel, dim3(1), dim3(256), 0, st, partials, blocks, mn_mx);
     return hipGetLastError();
 }
 
