@@ -228,9 +228,10 @@ int build_sym_plan(nb_sim *s)
             for (int w = 0; w < 4; ++w) owned_pairs += std::max(0, T - (4 * S + w));
         }
     }
-    // ~6000 workgroups per launch: measured at N=65536 (R=4): 4/8/16/32/64 source tiles per wave-set
-    // -> 1.27/1.26/1.29/1.38/1.52 ms.  A workgroup sweeps 4 rows x cl source tiles.
-    int cl = (int)(owned_pairs / 6144 / 4);
+    // A workgroup sweeps 4 rows x cl source tiles.  ~2000 workgroups per launch: with tail smoothing
+    // (below) measured at N=65536 (R=4): cl = 1/2/4/6/8/16 -> step 1.28/1.28/1.27/1.29/1.29/1.47 ms
+    // (small cl pays in row-slot traffic, large cl in load balance).
+    int cl = (int)(owned_pairs / 2048 / 4);
     cl = std::max(1, std::min(cl, 16));
     if (const char *e = getenv("NB_SYM_CL")) cl = std::max(1, atoi(e));
     // Tail smoothing.  Work items (4 rows x cl source tiles) all take the same time and the chip runs
