@@ -66,6 +66,10 @@ class GalaxySimulation:
             raise ValueError("positions, velocities and masses disagree on N")
 
         self._handle = C.c_void_p()
+        self._empty = self.num_stars == 0
+        if self._empty:
+            self._init_empty(positions, velocities, masses)
+            return
         self._cfg_dim = int(positions.shape[1])
         self._cache = {}        # name -> [tensor, version, dirty]
         self._native_acc = None
@@ -102,6 +106,29 @@ class GalaxySimulation:
         # simulation.py:69 (virtual call: subclasses may override _compute_accelerations)
         self.accelerations = self._compute_accelerations()
         self.tick = 0
+
+    # ------------------------------------------------------------------ N = 0
+    def _init_empty(self, positions, velocities, masses):
+        """Zero stars: nothing to launch.  Upstream returns empty tensors with the usual dtype
+        promotion, 0.0 / -0.0 energies, and the grid modes fail in `min()` of an empty tensor."""
+        if self.precision_mode in (PrecisionMode.INT8_SIM, PrecisionMode.INT4_SIM, PrecisionMode.CUSTOM):
+            raise RuntimeError("min(): cannot quantise an empty distance tensor (0 stars)")
+        self._cfg_dim = int(positions.shape[1])
+        self._cache = {}
+        self._native_acc = None
+        acc_dtype = torch.float64 if self.precision_mode == PrecisionMode.FLOAT64 else \
+            torch.promote_types(torch.promote_types(torch.float32, masses.dtype), positions.dtype)
+        self._empty_state = {
+            "positions": positions.clone().to(self.device), "velocities": velocities.clone().to(self.device),
+            "masses": masses.clone().to(self.device),
+            "accelerations": torch.zeros((0, self._cfg_dim), dtype=acc_dtype, device=self.device)}
+        self.tick = 0
+
+    def _step_empty(self):
+        st = self._empty_state
+        st["velocities"] = st["velocities"].to(torch.promote_types(st["velocities"].dtype, st["accelerations"].dtype))
+        st["positions"] = st["positions"].to(torch.promote_types(st["positions"].dtype, st["velocities"].dtype))
+        self.tick += 1
 
     # ------------------------------------------------------------------ native plumbing
     def __del__(self):
@@ -147,6 +174,8 @@ class GalaxySimulation:
         return self._cfg_dim
 
     def _get(self, name):
+        if self._empty:
+            return self._empty_state[name]
         ent = self._cache.get(name)
         if ent is None:
             t = self._download(name)
@@ -157,6 +186,9 @@ class GalaxySimulation:
     def _set(self, name, value):
         if not isinstance(value, torch.Tensor):
             raise TypeError(f"{name} must be a torch.Tensor")
+        if self._empty:
+            self._empty_state[name] = value
+            return
         if name == "accelerations" and value is self._native_acc:
             self._cache[name] = [value, value._version, False]     # produced by the library itself
         else:
@@ -202,6 +234,8 @@ class GalaxySimulation:
 
     def step(self):
         """One kick-drift-kick leapfrog step (reference simulation.py:120-143)."""
+        if self._empty:
+            return self._step_empty()
         L = N.lib()
         if self._overridden():
             self._flush()
@@ -220,7 +254,7 @@ class GalaxySimulation:
     def run(self, num_ticks: int, callback: Callable = None, callback_interval: int = 100):
         """Run `num_ticks` steps; `callback(self, self.tick)` every `callback_interval`
         (reference simulation.py:145-158)."""
-        fused = (not self._overridden()) and type(self).step is GalaxySimulation.step
+        fused = (not self._overridden()) and type(self).step is GalaxySimulation.step and not self._empty
         if not fused:
             for t in range(num_ticks):
                 self.step()
@@ -254,6 +288,8 @@ class GalaxySimulation:
 
     def get_kinetic_energy(self) -> float:
         """sum(0.5 * m * v^2) (reference simulation.py:170-174)."""
+        if self._empty:
+            return 0.0
         self._flush(("velocities", "masses"))
         ke = C.c_double()
         N.check(N.lib().nb_energy(self._handle, C.byref(ke), None))
@@ -261,6 +297,8 @@ class GalaxySimulation:
 
     def get_potential_energy(self) -> float:
         """-G * sum_{i<j} m_i m_j / sqrt(r_ij^2 + eps^2) (reference simulation.py:176-192)."""
+        if self._empty:
+            return -0.0
         self._flush(("positions", "masses"))
         pe = C.c_double()
         N.check(N.lib().nb_energy(self._handle, None, C.byref(pe)))
