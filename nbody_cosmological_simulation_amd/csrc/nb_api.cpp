@@ -462,17 +462,18 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         if (qhook >= 0 && s->logical[0] != NB_F64)
             return fail(NB_ERR_UNSUPPORTED, "mixed fp32 positions in fp64 storage under a cast mode");
         const int pa_f32 = (qhook < 0 && s->logical[0] == NB_F32);
-        used_sym = s->sym.enabled && !pa_f32 && qhook < 0;
+        const bool sym_default_shape = (c.dim == 2 && s->sym.r == 4) || (c.dim == 3 && s->sym.r == 2);
+        used_sym = s->sym.enabled && qhook < 0 && (!pa_f32 || sym_default_shape);
         sym_uniform = s->mass_uniform;
         if (used_sym) {
             const auto &sp = s->sym;
             if (!packed_ready)
                 HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, 1, 0, 0.0, 0.0,
-                                      c.G, s->stream));
+                                      c.G, pa_f32, s->stream));
             if (int rc = prof_begin(s, &slot)) return rc;
             HIPCHK(nb_launch_force_sym_f64((const double *)sp.packed, sp.work, sp.nwork, sp.rowslab,
-                                           (double *)sp.colslab, sp.np, c.dim, sp.r, s->mass_uniform, c.softening_sq,
-                                           s->stream));
+                                           (double *)sp.colslab, sp.np, c.dim, sp.r, s->mass_uniform, pa_f32,
+                                           c.softening_sq, s->stream));
             s->last_kernel = "force_sym_kernel<double";
             if (int rc = prof_end(s, slot)) return rc;
         } else {
@@ -524,7 +525,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
             const double gfac = (hook == HOOK_GRID) ? 1.0 : (double)(float)c.G;
             if (!packed_ready || hook == HOOK_GRID)
                 HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, 0, 0, 0.0, 0.0,
-                                      gfac, s->stream));
+                                      gfac, 0, s->stream));
             if (int rc = prof_begin(s, &slot)) return rc;
             HIPCHK(nb_launch_force_sym_f32((const float *)sp.packed, sp.work, sp.nwork, sp.rowslab,
                                            (float *)sp.colslab, sp.np, c.dim, sp.r, sym_uniform, hook, eps2, s->tab,
@@ -757,7 +758,7 @@ int nb_step(nb_sim *s, int32_t nsteps)
         if (fuse_pack) {
             HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, s->sym.packed, s->cfg.n, s->sym.np, s->cfg.dim,
                                   s->is_f64, pending_close ? 2 : 1, s->cfg.dt / 2, s->cfg.dt,
-                                  s->is_f64 ? s->cfg.G : (double)(float)s->cfg.G, s->stream));
+                                  s->is_f64 ? s->cfg.G : (double)(float)s->cfg.G, 0, s->stream));
         } else {
             if (pending_close) HIPCHK(nb_launch_axpy(s->vel, s->acc, s->cfg.dt / 2, nd(s), s->is_f64, s->stream));
             HIPCHK(nb_launch_kick_drift(s->pos, s->vel, s->acc, s->cfg.dt / 2, s->cfg.dt, nd(s), s->is_f64, s->stream));
@@ -795,7 +796,7 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential)
         if (pe_sym) {
             // same tile-pair work list as the force kernel; `packed` is scratch between force evaluations
             HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, s->is_f64, 0, 0.0, 0.0,
-                                  1.0, s->stream));
+                                  1.0, s->is_f64 && s->logical[0] != NB_F64, s->stream));
             HIPCHK(nb_launch_potential_sym(sp.packed, sp.work, sp.nwork, s->scratch, sp.np, c.dim, sp.r, s->is_f64,
                                            s->logical[0] != NB_F64, s->logical[2] != NB_F64, c.softening_sq, s->stream));
             HIPCHK(nb_launch_final_sum(s->scratch, sp.nwork, s->scalars + 3, s->stream));

@@ -106,11 +106,24 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
                 T d[D];
                 T w;
                 if constexpr (std::is_same_v<T, double>) {
+                    double q;
+                    if (HOOK == HOOK_F32PAIR) {
+                        // FLOAT64 mode on fp32-typed positions (first evaluation): diff and
+                        // r2 in fp32 in the reference's op order, everything after the hook in fp64
+                        float df[D];
 #pragma unroll
-                    for (int k = 0; k < D; ++k) d[k] = xj[rj][k] - xi[ri][k];
-                    double q = __builtin_fma(d[D - 1], d[D - 1], eps2);
+                        for (int k = 0; k < D; ++k) {
+                            df[k] = __fsub_rn((float)xj[rj][k], (float)xi[ri][k]);
+                            d[k] = (double)df[k];
+                        }
+                        q = (double)r2_f32_exact<D>(df, ga.gfac);       // gfac carries eps2 as fp32 here
+                    } else {
 #pragma unroll
-                    for (int k = D - 2; k >= 0; --k) q = __builtin_fma(d[k], d[k], q);
+                        for (int k = 0; k < D; ++k) d[k] = xj[rj][k] - xi[ri][k];
+                        q = __builtin_fma(d[D - 1], d[D - 1], eps2);
+#pragma unroll
+                        for (int k = D - 2; k >= 0; --k) q = __builtin_fma(d[k], d[k], q);
+                    }
                     w = inv_r3_sym(q, c15, c1875);
                 } else {
                     // reference op order, one rounding per op, no FMA (bit-identical r2)
@@ -275,13 +288,10 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
         for (int k = 0; k < D; ++k) rowslab[((size_t)slot * D + k) * B + r * 64 + lane] = ai_sum[r][k];
 }
 
-// Padding particles sit at PAD in every coordinate: r^2 stays finite, y0^3 underflows to exactly
-// 0 (fp64: r2 ~ 1e300, y0^3 ~ 1e-450; fp32: r2 ~ 1e36, y0^3 ~ 1e-54), so they contribute exactly
-// nothing whatever their mass; in grid modes they fall into the last bin and carry mass 0.
-template <typename T> __device__ __forceinline__ T pad_coord();
-template <> __device__ __forceinline__ double pad_coord<double>() { return 1e150; }
-template <> __device__ __forceinline__ float pad_coord<float>() { return 1e18f; }
-
+// Padding particles sit at `pad` in every coordinate (chosen by nb_launch_pack): r^2 stays finite and
+// y0^3 underflows to exactly 0 (fp64: r2 ~ 1e300, y0^3 ~ 1e-450; fp32: r2 ~ 1e36, y0^3 ~ 1e-54), so
+// they contribute exactly nothing whatever their mass; in grid modes they fall into the last bin and
+// carry mass 0.  (fp32 pair arithmetic on fp64 storage: pad = 1e18, contributions ~1e-37, absorbed.)
 template <typename T> __device__ __forceinline__ T axpy_rn(T a, T b, T s);
 template <> __device__ __forceinline__ double axpy_rn<double>(double a, double b, double s) { return __dadd_rn(a, __dmul_rn(b, s)); }
 template <> __device__ __forceinline__ float axpy_rn<float>(float a, float b, float s) { return __fadd_rn(a, __fmul_rn(b, s)); }
@@ -293,7 +303,7 @@ template <> __device__ __forceinline__ float axpy_rn<float>(float a, float b, fl
 template <typename T, int D, int KICK>
 __global__ void __launch_bounds__(NB_BLOCK)
 pack_kernel(T *__restrict__ pos, T *__restrict__ vel, const T *__restrict__ acc, const T *__restrict__ mass,
-            T *__restrict__ packed, int n, int np, T half_dt, T dt, T gfac)
+            T *__restrict__ packed, int n, int np, T half_dt, T dt, T gfac, T pad)
 {
     const int p = blockIdx.x * NB_BLOCK + threadIdx.x;
     if (p >= np) return;
@@ -315,7 +325,7 @@ pack_kernel(T *__restrict__ pos, T *__restrict__ vel, const T *__restrict__ acc,
         packed[(size_t)D * np + p] = gfac * mass[p];
     } else {
 #pragma unroll
-        for (int k = 0; k < D; ++k) packed[(size_t)k * np + p] = pad_coord<T>();
+        for (int k = 0; k < D; ++k) packed[(size_t)k * np + p] = pad;
         packed[(size_t)D * np + p] = (T)0;
     }
 }
@@ -493,12 +503,16 @@ hipError_t launch_sym_u(const T *packed, const SymWork *work, int nwork, double 
 }  // namespace
 
 hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mass, void *packed, int n, int np,
-                          int dim, int is_f64, int kick, double half_dt, double dt, double gfac, hipStream_t st)
+                          int dim, int is_f64, int kick, double half_dt, double dt, double gfac, int f32_pairs,
+                          hipStream_t st)
 {
+    // padding coordinate: far enough that r^-3 vanishes, close enough that r2 stays finite in the
+    // arithmetic the pair loop uses (fp32 pair arithmetic on fp64 storage needs the fp32 value)
+    const double pad = (is_f64 && !f32_pairs) ? 1e150 : 1e18;
     const int grid = (np + NB_BLOCK - 1) / NB_BLOCK;
 #define NB_PACK(TT, DD, KK) \
     hipLaunchKernelGGL((pack_kernel<TT, DD, KK>), dim3(grid), dim3(NB_BLOCK), 0, st, (TT *)pos, (TT *)vel, \
-                       (const TT *)acc, (const TT *)mass, (TT *)packed, n, np, (TT)half_dt, (TT)dt, (TT)gfac)
+                       (const TT *)acc, (const TT *)mass, (TT *)packed, n, np, (TT)half_dt, (TT)dt, (TT)gfac, (TT)pad)
 #define NB_PACK_K(TT, DD) do { if (kick == 2) NB_PACK(TT, DD, 2); else if (kick == 1) NB_PACK(TT, DD, 1); else NB_PACK(TT, DD, 0); } while (0)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64) { if (dim == 2) NB_PACK_K(double, 2); else NB_PACK_K(double, 3); }
@@ -509,8 +523,15 @@ hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mas
 }
 
 hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, int nwork, double *rowslab,
-                                   double *colslab, int np, int dim, int r, int uniform, double eps2, hipStream_t st)
+                                   double *colslab, int np, int dim, int r, int uniform, int pa_f32, double eps2,
+                                   hipStream_t st)
 {
+    if (pa_f32) {   // first evaluation on fp32-typed positions: default tile shapes only
+        const float e32 = (float)eps2;
+        if (dim == 2 && r == 4) return launch_sym_u<double, 2, 4, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st);
+        if (dim == 3 && r == 2) return launch_sym_u<double, 3, 2, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st);
+        return hipErrorInvalidValue;
+    }
     if (dim == 2 && r == 1) return launch_sym_u<double, 2, 1, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st);
     if (dim == 2 && r == 2) return launch_sym_u<double, 2, 2, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st);
     if (dim == 2 && r == 4) return launch_sym_u<double, 2, 4, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st);

@@ -12,7 +12,8 @@ constexpr int NB_TJ = 256;      // sources staged in LDS per tile (one per threa
 constexpr int NB_MAX_LUT = 256; // grid levels served by the LDS threshold table
 
 // hooks compiled into the pair loop (quantization.py:21-71)
-enum { HOOK_NONE = 0, HOOK_BF16 = 1, HOOK_F16 = 2, HOOK_GRID = 3 };
+enum { HOOK_NONE = 0, HOOK_BF16 = 1, HOOK_F16 = 2, HOOK_GRID = 3,
+       HOOK_F32PAIR = 4 /* fp64 state, diff/r2 in fp32: FLOAT64-mode first evaluation */ };
 
 // Device-resident grid tables written by grid_tables_kernel, read by the force kernel.
 struct GridTables {
@@ -63,9 +64,10 @@ struct SymWork {
 // pack positions + mass factors into padded component arrays; kick != 0 fuses the opening
 // kick + drift of a step (simulation.py:132,135)
 hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mass, void *packed, int n, int np,
-                          int dim, int is_f64, int kick, double half_dt, double dt, double gfac, hipStream_t st);
+                          int dim, int is_f64, int kick, double half_dt, double dt, double gfac, int f32_pairs,
+                          hipStream_t st);
 hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, int nwork, double *rowslab,
-                                   double *colslab, int np, int dim, int r, int uniform, double eps2,
+                                   double *colslab, int np, int dim, int r, int uniform, int pa_f32, double eps2,
                                    hipStream_t st);
 hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int nwork, double *rowslab,
                                    float *colslab, int np, int dim, int r, int uniform, int hook, float eps2,

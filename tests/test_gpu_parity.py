@@ -767,3 +767,26 @@ def test_2000_tick_horizon_fp64_vs_oracle(nb):
     print(f"2000 ticks: pos err {err:.2e} vel err {verr:.2e} drift {drift:.6e} (oracle {drift_ref:.6e})")
     assert err < 1e-10 and verr < 1e-9
     assert abs(drift - drift_ref) < 1e-10
+
+
+@pytest.mark.parametrize("n,d", [(5000, 2), (4500, 3)])
+def test_float64_mode_first_evaluation_on_fp32_state_ragged(nb, n, d):
+    """main.py's flow at a ragged N on the pair-symmetric path: fp32 tensors in FLOAT64 mode -> first force
+    with fp32 diff/r2, fp32-typed energies at tick 0, promotion to fp64 by the first step."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(n)
+    pos = (rng.standard_normal((n, d)) * 5).astype(np.float32)
+    vel = (rng.standard_normal((n, d)) * 0.05).astype(np.float32)
+    mass = (0.5 + rng.random(n)).astype(np.float32)
+    sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode.FLOAT64)
+    assert sim.force_kernel_name() == "force_sym_kernel<double"
+    ref = O.OracleSim(pos, vel, mass, "float64")
+    assert sim.accelerations.dtype == torch.float64 and sim.positions.dtype == torch.float32
+    assert relerr(sim.accelerations.numpy(), ref.accelerations) < 1e-13
+    assert abs(sim.get_potential_energy() - ref.get_potential_energy()) <= 2e-6 * abs(ref.get_potential_energy())
+    assert abs(sim.get_kinetic_energy() - ref.get_kinetic_energy()) <= 2e-6 * abs(ref.get_kinetic_energy())
+    sim.run(2)
+    ref.run(2)
+    assert sim.positions.dtype == torch.float64
+    assert relerr(sim.positions.numpy(), ref.positions) < 1e-13
+    assert abs(sim.get_potential_energy() - ref.get_potential_energy()) <= 1e-12 * abs(ref.get_potential_energy())
