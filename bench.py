@@ -69,12 +69,16 @@ def cpu_baseline(pos, vel, mass, target_s):
         import torch
         from oracle import torch_materialised as TM
         nr = 4096
-        rt, threads = TM.time_steps(pos[:nr].clone(), vel[:nr].clone(), mass[:nr].clone(), steps=5, warmup=1,
-                                    threads=os.cpu_count())
-        ref_form = {"value": nr * 5 / rt, "unit": "particle-steps/s", "n": nr, "threads": threads,
-                    "pair_interactions_per_s": float(nr) * nr * 5 / rt,
-                    "what": "reference formulation (materialised torch broadcasts, simulation.py:74-143) restated in "
-                            "oracle/torch_materialised.py, FLOAT64 mode, 5 steps"}
+        best = None
+        for threads in (None, 16):          # torch's default thread count (what a user gets), and 16
+            rt, used = TM.time_steps(pos[:nr].clone(), vel[:nr].clone(), mass[:nr].clone(), steps=3, warmup=1,
+                                     threads=threads)
+            row = {"value": nr * 3 / rt, "threads": used, "pair_interactions_per_s": float(nr) * nr * 3 / rt}
+            if best is None or row["value"] > best["value"]:
+                best = row
+        ref_form = dict(best, unit="particle-steps/s", n=nr,
+                        what="reference formulation (materialised torch broadcasts, simulation.py:74-143) restated "
+                             "in oracle/torch_materialised.py, FLOAT64 mode, 3 steps, best of torch-default / 16 threads")
     except Exception as exc:            # never let the context measurement break the bench line
         ref_form = {"error": repr(exc)}
     return {
