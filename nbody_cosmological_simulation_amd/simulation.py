@@ -66,6 +66,8 @@ class GalaxySimulation:
             raise ValueError("positions, velocities and masses disagree on N")
 
         self._handle = C.c_void_p()
+        self._serial = 0            # bumped whenever the device state changes (energy memo key)
+        self._energy_memo = {}
         self._empty = self.num_stars == 0
         if self._empty:
             self._init_empty(positions, velocities, masses)
@@ -141,6 +143,7 @@ class GalaxySimulation:
             h.value = None
 
     def _upload(self, name, tensor):
+        self._serial += 1
         t = tensor.detach()
         if t.dtype not in _TORCH_TO_NB:
             raise TypeError(f"{name}: unsupported dtype {t.dtype}")
@@ -213,6 +216,7 @@ class GalaxySimulation:
         N.check(N.lib().nb_set_params(self._handle, float(self.G), float(self.softening_sq), float(self.dt)))
 
     def _invalidate(self, *names):
+        self._serial += 1
         for name in names:
             self._cache.pop(name, None)
 
@@ -291,18 +295,26 @@ class GalaxySimulation:
         if self._empty:
             return 0.0
         self._flush(("velocities", "masses"))
-        ke = C.c_double()
-        N.check(N.lib().nb_energy(self._handle, C.byref(ke), None))
-        return ke.value
+        key = ("ke", self._serial, float(self.G))
+        if key not in self._energy_memo:       # main.py asks for the same energy up to 3x per callback
+            ke = C.c_double()
+            N.check(N.lib().nb_energy(self._handle, C.byref(ke), None))
+            self._energy_memo = {k: v for k, v in self._energy_memo.items() if k[1] == self._serial}
+            self._energy_memo[key] = ke.value
+        return self._energy_memo[key]
 
     def get_potential_energy(self) -> float:
         """-G * sum_{i<j} m_i m_j / sqrt(r_ij^2 + eps^2) (reference simulation.py:176-192)."""
         if self._empty:
             return -0.0
         self._flush(("positions", "masses"))
-        pe = C.c_double()
-        N.check(N.lib().nb_energy(self._handle, None, C.byref(pe)))
-        return pe.value
+        key = ("pe", self._serial, float(self.G), float(self.softening_sq))
+        if key not in self._energy_memo:       # O(N^2): memoised until the state or G / softening change
+            pe = C.c_double()
+            N.check(N.lib().nb_energy(self._handle, None, C.byref(pe)))
+            self._energy_memo = {k: v for k, v in self._energy_memo.items() if k[1] == self._serial}
+            self._energy_memo[key] = pe.value
+        return self._energy_memo[key]
 
     def get_total_energy(self) -> float:
         """Total mechanical energy (reference simulation.py:194-196)."""

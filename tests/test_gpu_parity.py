@@ -790,3 +790,19 @@ def test_float64_mode_first_evaluation_on_fp32_state_ragged(nb, n, d):
     assert sim.positions.dtype == torch.float64
     assert relerr(sim.positions.numpy(), ref.positions) < 1e-13
     assert abs(sim.get_potential_energy() - ref.get_potential_energy()) <= 1e-12 * abs(ref.get_potential_energy())
+
+
+def test_energy_memo_tracks_state_changes(nb):
+    """Energies are memoised per device state: repeated calls are free, any step / edit invalidates."""
+    g = load_golden("g1_n257_d2_e0.05.npz")
+    sim = mk(nb, g, "float64")
+    e0 = sim.get_total_energy()
+    assert sim.get_total_energy() == e0
+    sim.velocities[3, 0] += 0.5                      # in-place edit must be seen
+    e1 = sim.get_total_energy()
+    assert e1 != e0
+    sim.step()
+    assert sim.get_total_energy() != e1
+    pe = sim.get_potential_energy()
+    sim.G = 0.002                                    # attribute write changes the potential energy scale
+    assert abs(sim.get_potential_energy() - 2 * pe) <= 1e-12 * abs(pe)
