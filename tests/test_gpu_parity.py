@@ -806,3 +806,52 @@ def test_energy_memo_tracks_state_changes(nb):
     pe = sim.get_potential_energy()
     sim.G = 0.002                                    # attribute write changes the potential energy scale
     assert abs(sim.get_potential_energy() - 2 * pe) <= 1e-12 * abs(pe)
+
+
+def test_randomised_configurations_vs_oracle(nb, monkeypatch):
+    """Seeded sweep over (N, D, mode, softening, G, dt, masses, kernel family, steps): the engine must
+    track the oracle everywhere, not only on the hand-picked cases above."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(20261004)
+    modes = ["float64", "float64", "float32", "bfloat16", "float16", "int8_sim", "int4_sim", "custom"]
+    worst = {}
+    for case in range(48):
+        n = int(rng.integers(2, 700))
+        d = int(rng.choice([2, 3]))
+        mode = modes[case % len(modes)]
+        eps = float(rng.choice([0.01, 0.05, 0.1, 0.3]))
+        G = float(rng.choice([1e-3, 5e-3, 1e-2]))
+        dt = float(rng.choice([0.005, 0.01, 0.02]))
+        steps = int(rng.integers(1, 4))
+        sym = int(rng.integers(0, 2))
+        uniform = bool(rng.integers(0, 2))
+        f64_in = mode == "float64" and bool(rng.integers(0, 2))
+        dtype = np.float64 if f64_in else np.float32
+        pos = (rng.standard_normal((n, d)) * rng.choice([1.0, 5.0, 20.0])).astype(dtype)
+        vel = (rng.standard_normal((n, d)) * 0.05).astype(dtype)
+        mass = (np.full(n, 1.3) if uniform else 0.2 + 2 * rng.random(n)).astype(dtype)
+        monkeypatch.setenv("NB_SYM", str(sym))
+        if sym:
+            monkeypatch.setenv("NB_SYM_R", str(2 if d == 3 else int(rng.choice([2, 4]))))
+        sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode(mode), G=G,
+                                  softening=eps, dt=dt)
+        ref = O.OracleSim(pos, vel, mass, mode, G=G, softening=eps, dt=dt)
+        tag = f"case {case}: n={n} d={d} {mode} eps={eps} sym={sym} uniform={uniform} f64_in={f64_in}"
+        quant = mode in ("int8_sim", "int4_sim")
+        if mode in GRID:
+            dbg = O.accelerations(pos, mass, mode, G=G, softening=eps, debug=True)[1]
+            got = sim.quant_debug(bins=True)
+            assert np.array_equal(got["d2bins"], dbg["d2bins"]), tag
+            if quant and int((got["fbins"] != dbg["fbins"]).sum()) > 0:
+                continue                                  # a flipped force bin: trajectories legitimately differ
+        tol = 1e-12 if mode == "float64" else 3e-6
+        e = relerr(sim.accelerations.numpy(), ref.accelerations)
+        assert e < tol, (tag, e)
+        sim.run(steps)
+        ref.run(steps)
+        if not quant:
+            e2 = relerr(sim.positions.numpy(), ref.positions)
+            assert e2 < (1e-12 if mode == "float64" else 1e-5), (tag, e2)
+            assert str(sim.positions.dtype).replace("torch.", "") == str(ref.positions.dtype), tag
+        worst[mode] = max(worst.get(mode, 0.0), e)
+    print("worst single-evaluation errors:", {k: f"{v:.1e}" for k, v in worst.items()})
