@@ -461,9 +461,10 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         else if (c.mode == NB_FLOAT16) qhook = HOOK_F16;
         if (qhook >= 0 && s->logical[0] != NB_F64)
             return fail(NB_ERR_UNSUPPORTED, "mixed fp32 positions in fp64 storage under a cast mode");
-        const int pa_f32 = (qhook < 0 && s->logical[0] == NB_F32);
+        const int pair_dt = (qhook < 0 && s->logical[0] != NB_F64) ? s->logical[0] : -1;   // NB_F32 / F16 / BF16
+        const int pa_f32 = (pair_dt == NB_F32);
         const bool sym_default_shape = (c.dim == 2 && s->sym.r == 4) || (c.dim == 3 && s->sym.r == 2);
-        used_sym = s->sym.enabled && qhook < 0 && (!pa_f32 || sym_default_shape);
+        used_sym = s->sym.enabled && qhook < 0 && (pair_dt < 0 || (pa_f32 && sym_default_shape));
         sym_uniform = s->mass_uniform;
         if (used_sym) {
             const auto &sp = s->sym;
@@ -479,7 +480,8 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         } else {
             if (int rc = prof_begin(s, &slot)) return rc;
             HIPCHK(nb_launch_force_f64((const double *)s->pos, (const double *)s->mass, s->partial, s->geom, c.dim,
-                                       pa_f32, qhook, c.G, c.softening_sq, s->stream));
+                                       pair_dt, qhook, c.G, c.softening_sq,
+                                       (float)round_dt(pair_dt >= 0 ? pair_dt : NB_F32, c.softening_sq), s->stream));
             s->last_kernel = "force_f64_kernel";
             if (int rc = prof_end(s, slot)) return rc;
         }
@@ -657,9 +659,9 @@ int nb_set_state(nb_sim *s, const void *pos, const void *vel, const void *mass, 
     if (dtype < NB_F16 || dtype > NB_F64) return fail(NB_ERR_INVALID, "bad dtype %d", dtype);
     DeviceGuard guard(s->cfg.device);
     const int mode = s->cfg.mode;
-    if (is_half(dtype) && (mode == NB_FLOAT64 || grid_mode(mode)))
-        return fail(NB_ERR_UNSUPPORTED, "float16/bfloat16 state is implemented for the FLOAT32/BFLOAT16/FLOAT16 "
-                                        "precision modes only");
+    if (is_half(dtype) && grid_mode(mode))
+        return fail(NB_ERR_UNSUPPORTED, "float16/bfloat16 state under a grid (INT8/INT4/CUSTOM) precision mode is "
+                                        "not implemented");
     if (dtype == NB_F64 && grid_mode(mode))
         return fail(NB_ERR_UNSUPPORTED, "fp64 state with a grid (INT8/INT4/CUSTOM) precision mode is not implemented");
     const bool want_f64 = (mode == NB_FLOAT64) || dtype == NB_F64;

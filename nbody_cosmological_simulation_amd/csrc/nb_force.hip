@@ -53,6 +53,30 @@ __device__ __forceinline__ float inv_r3_f32(float q)
     return (y * y) * y;
 }
 
+// PA: arithmetic type of diff / r2.  NB_F32 normally; NB_F16 / NB_BF16 for the first evaluation on
+// half-typed state tensors (omega_point_test.py:722-733): every op of simulation.py:83-86 rounds to
+// the half type, the D-term sum accumulates in float and rounds once (torch opmath), eps2 enters
+// as a half scalar.
+template <int PA> __device__ __forceinline__ float round_pa(float x)
+{
+    if (PA == NB_F16) return round_f16(x);
+    if (PA == NB_BF16) return round_bf16(x);
+    return x;
+}
+template <int D, int PA>
+__device__ __forceinline__ float r2_half_state(const float *xi, const float *xj, float eps2_pa, float *d)
+{
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        d[k] = round_pa<PA>(__fsub_rn(xj[k], xi[k]));
+        const float sq = round_pa<PA>(__fmul_rn(d[k], d[k]));
+        s = (k == 0) ? sq : __fadd_rn(s, sq);
+    }
+    s = round_pa<PA>(s);
+    return round_pa<PA>(__fadd_rn(s, eps2_pa));
+}
+
 // ------------------------------------------------------------------------------------------
 // fp64 state (FLOAT64 mode).  PA_F32: diff and r2 in fp32 (first evaluation on fp32-typed
 // positions), everything after the hook in fp64.
@@ -61,7 +85,9 @@ __device__ __forceinline__ float inv_r3_f32(float q)
 // :722-733 builds such sims): diff and r2 in fp64 in the reference's op order, the hook casts r2
 // to fp32 (and through the half type), q^1.5 and G/. stay fp32, the product with the fp64 mass and
 // everything after it is fp64 again (torch promotion).
-template <int D, int R, bool PA_F32, int QHOOK = -1>
+// PAIR: -1 = fp64 pair arithmetic; NB_F32 / NB_F16 / NB_BF16 = the dtype the positions are typed as
+// (first evaluation before the state has been promoted to fp64).
+template <int D, int R, int PAIR, int QHOOK = -1>
 __global__ void __launch_bounds__(NB_BLOCK)
 force_f64_kernel(const double *__restrict__ pos, const double *__restrict__ mass,
                  double *__restrict__ partial, ForceGeom g, double G, double eps2, float eps2_f)
@@ -122,7 +148,7 @@ force_f64_kernel(const double *__restrict__ pos, const double *__restrict__ mass
                     for (int k = 0; k < D; ++k) acc[r][k] = __builtin_fma(w, d[k], acc[r][k]);
                     continue;
                 }
-                if (PA_F32) {
+                if (PAIR == NB_F32) {
                     float df[D];
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
@@ -130,6 +156,13 @@ force_f64_kernel(const double *__restrict__ pos, const double *__restrict__ mass
                         d[k] = (double)df[k];
                     }
                     q = (double)r2_f32_exact<D>(df, eps2_f);
+                } else if (PAIR == NB_F16 || PAIR == NB_BF16) {
+                    float xif[D], xjf[D], df[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) { xif[k] = (float)xi[r][k]; xjf[k] = (float)xj[k]; }
+                    q = (double)r2_half_state<D, PAIR>(xif, xjf, eps2_f, df);     // eps2_f already half-rounded
+#pragma unroll
+                    for (int k = 0; k < D; ++k) d[k] = (double)df[k];
                 } else {
 #pragma unroll
                     for (int k = 0; k < D; ++k) d[k] = xj[k] - xi[r][k];
@@ -159,30 +192,6 @@ force_f64_kernel(const double *__restrict__ pos, const double *__restrict__ mass
 // ------------------------------------------------------------------------------------------
 // fp32 state (FLOAT32 / BFLOAT16 / FLOAT16 / INT8 / INT4 / CUSTOM modes)
 // ------------------------------------------------------------------------------------------
-// PA: arithmetic type of diff / r2.  NB_F32 normally; NB_F16 / NB_BF16 for the first evaluation on
-// half-typed state tensors (omega_point_test.py:722-733): every op of simulation.py:83-86 rounds to
-// the half type, the D-term sum accumulates in float and rounds once (torch opmath), eps2 enters
-// as a half scalar.
-template <int PA> __device__ __forceinline__ float round_pa(float x)
-{
-    if (PA == NB_F16) return round_f16(x);
-    if (PA == NB_BF16) return round_bf16(x);
-    return x;
-}
-template <int D, int PA>
-__device__ __forceinline__ float r2_half_state(const float *xi, const float *xj, float eps2_pa, float *d)
-{
-    float s = 0.0f;
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        d[k] = round_pa<PA>(__fsub_rn(xj[k], xi[k]));
-        const float sq = round_pa<PA>(__fmul_rn(d[k], d[k]));
-        s = (k == 0) ? sq : __fadd_rn(s, sq);
-    }
-    s = round_pa<PA>(s);
-    return round_pa<PA>(__fadd_rn(s, eps2_pa));
-}
-
 template <int D, int R, int HOOK, int LP, int PA = NB_F32>
 __global__ void __launch_bounds__(NB_BLOCK)
 force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
@@ -685,23 +694,26 @@ hipError_t dispatch_dim(int dim, F &&f)
 constexpr int R_F32 = 2;
 
 hipError_t nb_launch_force_f64(const double *pos, const double *mass, double *partial, const ForceGeom &g,
-                               int dim, int pa_f32, int qhook, double G, double eps2_py, hipStream_t st)
+                               int dim, int pair_dt, int qhook, double G, double eps2_py, float eps2_pair,
+                               hipStream_t st)
 {
-    const int r = (pa_f32 || qhook >= 0) ? 2 : g.r;   // the special variants are compiled for R = 2 only
+    // pair_dt: -1 (fp64 pairs) or the dtype the positions are typed as (NB_F32 / NB_F16 / NB_BF16)
+    const int r = (pair_dt >= 0 || qhook >= 0) ? 2 : g.r;   // the special variants are compiled for R = 2 only
     const dim3 grid((g.n + NB_BLOCK * r - 1) / (NB_BLOCK * r), g.nchunks);
-    const float e32 = (float)eps2_py;
 #define NB_F64(DD, RR, PA, QH) \
-    hipLaunchKernelGGL((force_f64_kernel<DD, RR, PA, QH>), grid, dim3(NB_BLOCK), 0, st, pos, mass, partial, g, G, eps2_py, e32)
+    hipLaunchKernelGGL((force_f64_kernel<DD, RR, PA, QH>), grid, dim3(NB_BLOCK), 0, st, pos, mass, partial, g, G, eps2_py, eps2_pair)
     return dispatch_dim(dim, [&](auto D) {
         constexpr int DD = decltype(D)::value;
-        if (qhook == HOOK_NONE) NB_F64(DD, 2, false, HOOK_NONE);
-        else if (qhook == HOOK_BF16) NB_F64(DD, 2, false, HOOK_BF16);
-        else if (qhook == HOOK_F16) NB_F64(DD, 2, false, HOOK_F16);
+        if (qhook == HOOK_NONE) NB_F64(DD, 2, -1, HOOK_NONE);
+        else if (qhook == HOOK_BF16) NB_F64(DD, 2, -1, HOOK_BF16);
+        else if (qhook == HOOK_F16) NB_F64(DD, 2, -1, HOOK_F16);
         else if (qhook >= 0) return hipErrorInvalidValue;
-        else if (pa_f32) NB_F64(DD, 2, true, -1);
-        else if (g.r == 1) NB_F64(DD, 1, false, -1);
-        else if (g.r == 2) NB_F64(DD, 2, false, -1);
-        else NB_F64(DD, 4, false, -1);
+        else if (pair_dt == NB_F32) NB_F64(DD, 2, NB_F32, -1);
+        else if (pair_dt == NB_F16) NB_F64(DD, 2, NB_F16, -1);
+        else if (pair_dt == NB_BF16) NB_F64(DD, 2, NB_BF16, -1);
+        else if (g.r == 1) NB_F64(DD, 1, -1, -1);
+        else if (g.r == 2) NB_F64(DD, 2, -1, -1);
+        else NB_F64(DD, 4, -1, -1);
         return hipGetLastError();
     });
 #undef NB_F64

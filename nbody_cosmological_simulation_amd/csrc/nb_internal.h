@@ -87,7 +87,8 @@ hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, cons
 // qhook >= 0: fp64 positions under a cast mode (hook output fp32); pa: NB_F32, or NB_F16 / NB_BF16 for
 // the first evaluation on half-typed state (eps2 then already rounded to that type).
 hipError_t nb_launch_force_f64(const double *pos, const double *mass, double *partial, const ForceGeom &g,
-                               int dim, int pa_f32, int qhook, double G, double eps2_py, hipStream_t st);
+                               int dim, int pair_dt, int qhook, double G, double eps2_py, float eps2_pair,
+                               hipStream_t st);
 hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *partial, const ForceGeom &g,
                                int dim, int hook, int pa, float G, float eps2, const GridTables *tab,
                                hipStream_t st);

@@ -527,7 +527,11 @@ hipError_t nb_launch_kinetic(const void *vel, const void *mass, int n, int dim, 
     int blocks = (n + NB_BLOCK - 1) / NB_BLOCK;
     if (blocks > 1024) blocks = 1024;
     if (is_f64) {
-        if (vel_f32_logical)
+        if (half_pa == NB_F16)
+            hipLaunchKernelGGL((kinetic_kernel<double, true, NB_F16>), dim3(blocks), dim3(NB_BLOCK), 0, st, (const double *)vel, (const double *)mass, n, dim, scratch);
+        else if (half_pa == NB_BF16)
+            hipLaunchKernelGGL((kinetic_kernel<double, true, NB_BF16>), dim3(blocks), dim3(NB_BLOCK), 0, st, (const double *)vel, (const double *)mass, n, dim, scratch);
+        else if (vel_f32_logical)
             hipLaunchKernelGGL((kinetic_kernel<double, true>), dim3(blocks), dim3(NB_BLOCK), 0, st, (const double *)vel, (const double *)mass, n, dim, scratch);
         else
             hipLaunchKernelGGL((kinetic_kernel<double, false>), dim3(blocks), dim3(NB_BLOCK), 0, st, (const double *)vel, (const double *)mass, n, dim, scratch);
@@ -551,7 +555,13 @@ hipError_t nb_launch_potential(const void *pos, const void *mass, const ForceGeo
 #define NB_PE(T, D, PA) \
     hipLaunchKernelGGL((potential_kernel<T, D, PA>), grid, dim3(NB_BLOCK), 0, st, (const T *)pos, (const T *)mass, g, eps2_py, e32, mass_f32, scratch)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
-    if (is_f64) {
+    if (is_f64 && half_pa == NB_F16) {
+        if (dim == 2) hipLaunchKernelGGL((potential_kernel<double, 2, true, NB_F16>), grid, dim3(NB_BLOCK), 0, st, (const double *)pos, (const double *)mass, g, eps2_py, e32, mass_f32, scratch);
+        else hipLaunchKernelGGL((potential_kernel<double, 3, true, NB_F16>), grid, dim3(NB_BLOCK), 0, st, (const double *)pos, (const double *)mass, g, eps2_py, e32, mass_f32, scratch);
+    } else if (is_f64 && half_pa == NB_BF16) {
+        if (dim == 2) hipLaunchKernelGGL((potential_kernel<double, 2, true, NB_BF16>), grid, dim3(NB_BLOCK), 0, st, (const double *)pos, (const double *)mass, g, eps2_py, e32, mass_f32, scratch);
+        else hipLaunchKernelGGL((potential_kernel<double, 3, true, NB_BF16>), grid, dim3(NB_BLOCK), 0, st, (const double *)pos, (const double *)mass, g, eps2_py, e32, mass_f32, scratch);
+    } else if (is_f64) {
         if (pa_f32) { if (dim == 2) NB_PE(double, 2, true); else NB_PE(double, 3, true); }
         else        { if (dim == 2) NB_PE(double, 2, false); else NB_PE(double, 3, false); }
     } else if (half_pa == NB_F16) {

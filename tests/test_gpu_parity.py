@@ -399,8 +399,9 @@ def test_nan_inf_propagate_silently(nb):
 def test_errors_are_exceptions(nb):
     with pytest.raises(ValueError):
         nb.GalaxySimulation(torch.zeros(4, 4), torch.zeros(4, 4), torch.ones(4))
-    with pytest.raises(Exception):
-        nb.GalaxySimulation(torch.zeros(4, 2).half(), torch.zeros(4, 2).half(), torch.ones(4).half())
+    with pytest.raises(RuntimeError, match="not implemented"):       # documented gap: half-typed state + grid mode
+        nb.GalaxySimulation(torch.zeros(4, 2).half(), torch.zeros(4, 2).half(), torch.ones(4).half(),
+                            precision_mode=nb.PrecisionMode.INT8_SIM)
 
 
 def test_rccl_path_with_one_rank_communicator():
@@ -855,3 +856,23 @@ def test_randomised_configurations_vs_oracle(nb, monkeypatch):
             assert str(sim.positions.dtype).replace("torch.", "") == str(ref.positions.dtype), tag
         worst[mode] = max(worst.get(mode, 0.0), e)
     print("worst single-evaluation errors:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("name,code", [("float16", 0), ("bfloat16", 1)])
+def test_half_precision_state_in_float64_mode(nb, name, code):
+    """Default precision mode with f16 / bf16 tensors: half arithmetic for diff/r2 and the tick-0 energies,
+    fp64 from the hook on, fp64 state after the first step (torch promotion)."""
+    from oracle import oracle as O
+    g = load_golden("g4_api.npz")
+    tdt = getattr(torch, name)
+    pos, vel, mass = (T(g[k]).to(tdt) for k in ("pos", "vel", "mass"))
+    sim = nb.GalaxySimulation(pos, vel, mass, precision_mode=nb.PrecisionMode.FLOAT64, G=0.001, dt=0.01, softening=0.1)
+    ref = O.OracleSim(pos.float().numpy(), vel.float().numpy(), mass.float().numpy(), "float64", codes=(code, code, code))
+    assert sim.accelerations.dtype == torch.float64 and sim.positions.dtype == tdt
+    assert relerr(sim.accelerations.numpy(), ref.accelerations) < 1e-13
+    assert abs(sim.get_potential_energy() - ref.get_potential_energy()) <= 1e-2 * abs(ref.get_potential_energy())
+    sim.run(3)
+    ref.run(3)
+    assert sim.positions.dtype == torch.float64 and sim.velocities.dtype == torch.float64
+    assert relerr(sim.positions.numpy(), ref.positions) < 1e-13
+    assert relerr(sim.velocities.numpy(), ref.velocities) < 1e-12
