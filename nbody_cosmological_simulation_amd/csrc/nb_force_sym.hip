@@ -174,6 +174,80 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
     }
 }
 
+// fp32 sweep on packed pairs.  A lone wave issues one VALU instruction per ~4.6 cycles, i.e. half the
+// fp32 rate, so the scalar fp32 loop needs two ready waves at all times and loses ~25 % to stalls;
+// v_pk_{add,mul,fma}_f32 do two lanes' worth per issue.  Source slots (rj, rj+1) ride in the two halves
+// of a float2, so d, r2, the correction, the mass factors and both accumulations are packed; only
+// v_rsq_f32, the half-precision converts and the grid lookups stay per component.  Arithmetic is
+// identical to the scalar form (same operations, same order; -ffp-contract=off keeps r2 unfused).
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 rot1_f2(f2 v, int addr) { return f2{rot1<float>(v.x, addr), rot1<float>(v.y, addr)}; }
+
+template <int D, int R, bool DIAG, bool UNIFORM, int HOOK, bool EST>
+__device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&gi)[R], f2 (&ai2)[R][D],
+                                         f2 (&xj2)[R / 2][D], f2 (&gj2)[R / 2], f2 (&aj2)[R / 2][D], float eps2,
+                                         int rot_addr, const GridArgs &ga, int nsteps)
+{
+    const f2 c15 = {1.5f, 1.5f}, one = {1.0f, 1.0f};
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+        for (int h = 0; h < R / 2; ++h) {
+#pragma unroll
+            for (int ri = 0; ri < R; ++ri) {
+                f2 d[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) d[k] = xj2[h][k] - xi[ri][k];
+                f2 r2 = d[0] * d[0] + d[1] * d[1];          // one rounding per op (contraction is off)
+                if (D == 3) r2 = r2 + d[2] * d[2];
+                r2 = r2 + eps2;
+                f2 w;
+                if (HOOK == HOOK_GRID) {
+                    if (ga.degenerate) {
+                        w.x = inv_r3_sym((r2.x < 0.01f) ? 0.01f : r2.x, 1.5f, 0.0f) * ga.gfac;
+                        w.y = inv_r3_sym((r2.y < 0.01f) ? 0.01f : r2.y, 1.5f, 0.0f) * ga.gfac;
+                    } else if (EST) {
+                        w.x = ga.lut[grid_bin_estimate(ga.thr, r2.x, ga.est_a, ga.est_b, ga.lmax_bin)];
+                        w.y = ga.lut[grid_bin_estimate(ga.thr, r2.y, ga.est_a, ga.est_b, ga.lmax_bin)];
+                    } else {
+                        w.x = ga.lut[grid_bin_lookup<NB_MAX_LUT>(ga.thr, r2.x)];
+                        w.y = ga.lut[grid_bin_lookup<NB_MAX_LUT>(ga.thr, r2.y)];
+                    }
+                } else {
+                    f2 q = r2;
+                    if (HOOK == HOOK_BF16) q = f2{(float)(__bf16)r2.x, (float)(__bf16)r2.y};
+                    if (HOOK == HOOK_F16) q = f2{(float)(_Float16)r2.x, (float)(_Float16)r2.y};
+                    const f2 y0 = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+                    const f2 y02 = y0 * y0;
+                    const f2 e = __builtin_elementwise_fma(-q, y02, one);
+                    const f2 v = y0 * y02;
+                    const f2 ve = v * e;
+                    w = __builtin_elementwise_fma(ve, c15, v);
+                    if (HOOK == HOOK_F16) {      // fp16 overflow: q = +inf -> zero force upstream
+                        w.x = (q.x == __builtin_inff()) ? 0.0f : w.x;
+                        w.y = (q.y == __builtin_inff()) ? 0.0f : w.y;
+                    }
+                }
+                const f2 wj = UNIFORM ? w : w * gj2[h];
+#pragma unroll
+                for (int k = 0; k < D; ++k) ai2[ri][k] = __builtin_elementwise_fma(wj, d[k], ai2[ri][k]);
+                if (!DIAG) {
+                    const f2 wi = UNIFORM ? w : w * gi[ri];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) aj2[h][k] = __builtin_elementwise_fma(-wi, d[k], aj2[h][k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                xj2[h][k] = rot1_f2(xj2[h][k], rot_addr);
+                if (!DIAG) aj2[h][k] = rot1_f2(aj2[h][k], rot_addr);
+            }
+            if (!UNIFORM) gj2[h] = rot1_f2(gj2[h], rot_addr);
+        }
+    }
+}
+
 // T = double: FLOAT64 mode on fp64 state.  T = float: every fp32-state mode (HOOK selects it).
 // packed  [D+1][NP] of T : x, y, (z), mass factor (G*m, or m for HOOK_GRID whose LUT carries G);
 //                          padding particles sit far away (see pack_kernel).
@@ -233,30 +307,65 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
 #pragma unroll
             for (int k = 0; k < D; ++k) aj[r][k] = (T)0;
         if (J >= I) {                                   // wave-uniform; tiles below the diagonal belong to other rows
-            T xj[R][D], gj[R], ai[R][D];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                // a split sweep starts s_begin rotation steps in: lane l meets particle (l + s_begin) first
-                const int p = J * B + r * 64 + ((lane + wk.s_begin) & 63);
-#pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    xj[r][k] = packed[(size_t)k * np + p];
-                    ai[r][k] = F32 ? (T)0 : (T)ai_sum[r][k];
-                }
-                gj[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
-            }
             const bool diag = (J == I);
-            if (HOOK == HOOK_GRID && use_est) {
-                if (diag) sweep<T, D, R, true, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
-                else sweep<T, D, R, false, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+            if constexpr (F32 && (R % 2 == 0) && HOOK != HOOK_GRID) {
+                // fp32 cast modes: source slots (2h, 2h+1) packed in float2 halves (sweep_pk).  The grid hook
+                // keeps the scalar loop: its per-component lookups do not pack and the packed form spills.
+                f2 xj2[R / 2][D], gj2[R / 2], aj2[R / 2][D], ai2[R][D];
+#pragma unroll
+                for (int h = 0; h < R / 2; ++h) {
+                    // a split sweep starts s_begin rotation steps in: lane l meets particle (l + s_begin) first
+                    const int p0 = J * B + (2 * h) * 64 + ((lane + wk.s_begin) & 63);
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        xj2[h][k] = f2{packed[(size_t)k * np + p0], packed[(size_t)k * np + p0 + 64]};
+                        aj2[h][k] = f2{0.0f, 0.0f};
+                    }
+                    gj2[h] = UNIFORM ? f2{1.0f, 1.0f} : f2{packed[(size_t)D * np + p0], packed[(size_t)D * np + p0 + 64]};
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int k = 0; k < D; ++k) ai2[r][k] = f2{0.0f, 0.0f};
+                if (HOOK == HOOK_GRID && use_est) {
+                    if (diag) sweep_pk<D, R, true, UNIFORM, HOOK, true>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    else sweep_pk<D, R, false, UNIFORM, HOOK, true>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                } else {
+                    if (diag) sweep_pk<D, R, true, UNIFORM, HOOK, false>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    else sweep_pk<D, R, false, UNIFORM, HOOK, false>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                }
+#pragma unroll
+                for (int h = 0; h < R / 2; ++h)
+#pragma unroll
+                    for (int k = 0; k < D; ++k) { aj[2 * h][k] = aj2[h][k].x; aj[2 * h + 1][k] = aj2[h][k].y; }
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int k = 0; k < D; ++k) ai_sum[r][k] += (double)(ai2[r][k].x + ai2[r][k].y);
             } else {
-                if (diag) sweep<T, D, R, true, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
-                else sweep<T, D, R, false, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                T xj[R][D], gj[R], ai[R][D];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int p = J * B + r * 64 + ((lane + wk.s_begin) & 63);
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        xj[r][k] = packed[(size_t)k * np + p];
+                        ai[r][k] = F32 ? (T)0 : (T)ai_sum[r][k];
+                    }
+                    gj[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
+                }
+                if (HOOK == HOOK_GRID && use_est) {
+                    if (diag) sweep<T, D, R, true, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                    else sweep<T, D, R, false, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                } else {
+                    if (diag) sweep<T, D, R, true, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                    else sweep<T, D, R, false, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int k = 0; k < D; ++k) ai_sum[r][k] = F32 ? ai_sum[r][k] + (double)ai[r][k] : (double)ai[r][k];
             }
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int k = 0; k < D; ++k) ai_sum[r][k] = F32 ? ai_sum[r][k] + (double)ai[r][k] : (double)ai[r][k];
         }
         // column contributions of the super-row to tile J: the diagonal sweep leaves aj untouched (0),
         // skipped waves hold 0; add the four waves in a fixed order and write ONE slab entry.
