@@ -77,6 +77,7 @@ __device__ __forceinline__ float inv_r3_sym(float q, float c15, float)
 
 struct GridArgs {
     const float *thr, *lut;
+    const float4 *rec;      // rec[k] = {thr[k+1], lut[k], lut[k+1], -} for the one-access estimate path
     float est_a, est_b, gfac;
     int lmax_bin;
     bool degenerate;
@@ -136,7 +137,7 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
                         if (ga.degenerate) {
                             w = inv_r3_sym((r2 < 0.01f) ? 0.01f : r2, c15, c1875) * ga.gfac;
                         } else if (EST) {
-                            w = ga.lut[grid_bin_estimate(ga.thr, r2, ga.est_a, ga.est_b, ga.lmax_bin)];
+                            w = grid_w_estimate(ga.rec, r2, ga.est_a, ga.est_b, ga.lmax_bin - 1);
                         } else {
                             w = ga.lut[grid_bin_lookup<NB_MAX_LUT>(ga.thr, r2)];   // (1/q^1.5)*G
                         }
@@ -208,8 +209,8 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                         w.x = inv_r3_sym((r2.x < 0.01f) ? 0.01f : r2.x, 1.5f, 0.0f) * ga.gfac;
                         w.y = inv_r3_sym((r2.y < 0.01f) ? 0.01f : r2.y, 1.5f, 0.0f) * ga.gfac;
                     } else if (EST) {
-                        w.x = ga.lut[grid_bin_estimate(ga.thr, r2.x, ga.est_a, ga.est_b, ga.lmax_bin)];
-                        w.y = ga.lut[grid_bin_estimate(ga.thr, r2.y, ga.est_a, ga.est_b, ga.lmax_bin)];
+                        w.x = grid_w_estimate(ga.rec, r2.x, ga.est_a, ga.est_b, ga.lmax_bin - 1);
+                        w.y = grid_w_estimate(ga.rec, r2.y, ga.est_a, ga.est_b, ga.lmax_bin - 1);
                     } else {
                         w.x = ga.lut[grid_bin_lookup<NB_MAX_LUT>(ga.thr, r2.x)];
                         w.y = ga.lut[grid_bin_lookup<NB_MAX_LUT>(ga.thr, r2.y)];
@@ -265,12 +266,13 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
     __shared__ T s_aj[W][R][D][64];
     __shared__ float s_thr[HOOK == HOOK_GRID ? NB_MAX_LUT + 1 : 1];
     __shared__ float s_lut[HOOK == HOOK_GRID ? NB_MAX_LUT : 1];
+    __shared__ float4 s_rec[HOOK == HOOK_GRID ? NB_MAX_LUT : 1];
 
     const SymWork wk = work[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int I = wk.tile_i + wave;             // this wave's target tile (wave-uniform)
     const int rot_addr = ((lane + 1) & 63) << 2;
-    GridArgs ga{s_thr, s_lut, 0.0f, 0.0f, gfac, 0, false};
+    GridArgs ga{s_thr, s_lut, s_rec, 0.0f, 0.0f, gfac, 0, false};
     bool use_est = false;
     if (HOOK == HOOK_GRID) {
         const int levels = tab->levels;
@@ -284,6 +286,9 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
         ga.est_b = tab->est_b;
         ga.lmax_bin = levels - 1;
         use_est = tab->use_est != 0;
+        __syncthreads();
+        for (int k = threadIdx.x; k < NB_MAX_LUT; k += NB_BLOCK)
+            s_rec[k] = make_float4(s_thr[k + 1], s_lut[k], s_lut[min(k + 1, NB_MAX_LUT - 1)], 0.0f);
         __syncthreads();
     }
 
