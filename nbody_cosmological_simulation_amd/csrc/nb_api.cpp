@@ -529,9 +529,11 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
                 HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, 0, 0, 0.0, 0.0,
                                       gfac, 0, s->stream));
             if (int rc = prof_begin(s, &slot)) return rc;
+            // grid modes: the uniform kernel applies the common mass itself (reduce scale stays 1)
             HIPCHK(nb_launch_force_sym_f32((const float *)sp.packed, sp.work, sp.nwork, sp.rowslab,
-                                           (float *)sp.colslab, sp.np, c.dim, sp.r, sym_uniform, hook, eps2, s->tab,
-                                           (float)c.G, s->stream));
+                                           (float *)sp.colslab, sp.np, c.dim, sp.r,
+                                           hook == HOOK_GRID ? s->mass_uniform : sym_uniform, hook, eps2, s->tab,
+                                           (float)c.G, (float)s->mass_value, s->stream));
             s->last_kernel = "force_sym_kernel<float";
             if (int rc = prof_end(s, slot)) return rc;
         } else {

@@ -39,6 +39,16 @@ __device__ __forceinline__ int grid_bin_estimate(const float *thr, float r2, flo
     return k0 - ((r2 < lo) ? 1 : 0) + ((r2 >= hi) ? 1 : 0);
 }
 
+// Floor form of the estimate: with k0 = floor(estimate) the exact bin is k0 or k0 + 1, so ONE
+// threshold (thr[k0+1]) settles it.  kmax = levels - 2.
+__device__ __forceinline__ int grid_bin_floor_estimate(const float *thr, float r2, float est_a, float est_b, int kmax)
+{
+    const float ne = __builtin_fmaf(__builtin_amdgcn_logf(r2), est_a, est_b);
+    int k0 = (int)ne;
+    k0 = min(max(k0, 0), kmax);
+    return k0 + ((r2 >= thr[k0 + 1]) ? 1 : 0);
+}
+
 // Same guarantee, one LDS access: with k0 = floor(estimate) the exact bin is k0 or k0 + 1 (the exact
 // index is rint() of a value the estimate tracks to << 0.5), so a record {thr[k0+1], lut[k0], lut[k0+1]}
 // decides it with one compare.  Returns the force factor (1/q^1.5)*G of the exact bin.

@@ -654,6 +654,7 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
         tab->r2max = r2max;
         tab->degenerate = (range < 1e-10f) ? 1 : 0;
         tab->levels = levels;
+        tab->uniform_ok = (tab->use_est && r2max < 1e30f) ? 1 : 0;   // false for NaN / inf r2max too
     }
 }
 

@@ -89,7 +89,7 @@ struct GridArgs {
 // UNIFORM: all masses equal -> the mass factor is applied once to the finished sums
 //          (reduce_sym_kernel), saving both mass multiplies and the rotation of the masses.
 // HOOK:    precision hook applied to the fp32 r2 (HOOK_NONE for fp64); EST: grid bins by estimate.
-template <typename T, int D, int R, bool DIAG, bool UNIFORM, int HOOK, bool EST>
+template <typename T, int D, int R, bool DIAG, bool UNIFORM, int HOOK, int EST>
 __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (&ai)[R][D], T (&xj)[R][D],
                                       T (&gj)[R], T (&aj)[R][D], T eps2, int rot_addr, const GridArgs &ga,
                                       int nsteps)
@@ -136,8 +136,10 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
                     if (HOOK == HOOK_GRID) {
                         if (ga.degenerate) {
                             w = inv_r3_sym((r2 < 0.01f) ? 0.01f : r2, c15, c1875) * ga.gfac;
-                        } else if (EST) {
+                        } else if (EST == 1) {
                             w = grid_w_estimate(ga.rec, r2, ga.est_a, ga.est_b, ga.lmax_bin - 1);
+                        } else if (EST == 2) {
+                            w = ga.lut[grid_bin_floor_estimate(ga.thr, r2, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
                         } else {
                             w = ga.lut[grid_bin_lookup<NB_MAX_LUT>(ga.thr, r2)];   // (1/q^1.5)*G
                         }
@@ -258,14 +260,14 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
 template <typename T, int D, int R, bool UNIFORM, int HOOK>
 __global__ void __launch_bounds__(NB_BLOCK, 4)
 force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work, double *__restrict__ rowslab,
-                 T *__restrict__ colslab, int np, T eps2, const GridTables *__restrict__ tab, float gfac)
+                 T *__restrict__ colslab, int np, T eps2, const GridTables *__restrict__ tab, float gfac, int gate)
 {
     constexpr int B = 64 * R;
     constexpr int W = NB_BLOCK / 64;
     constexpr bool F32 = std::is_same_v<T, float>;
     __shared__ T s_aj[W][R][D][64];
     __shared__ float s_thr[HOOK == HOOK_GRID ? NB_MAX_LUT + 1 : 1];
-    __shared__ float s_lut[HOOK == HOOK_GRID ? NB_MAX_LUT : 1];
+    __shared__ float s_lut[HOOK == HOOK_GRID ? NB_MAX_LUT + 1 : 1];
     __shared__ float4 s_rec[HOOK == HOOK_GRID ? NB_MAX_LUT : 1];
 
     const SymWork wk = work[blockIdx.x];
@@ -273,22 +275,32 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
     const int I = wk.tile_i + wave;             // this wave's target tile (wave-uniform)
     const int rot_addr = ((lane + 1) & 63) << 2;
     GridArgs ga{s_thr, s_lut, s_rec, 0.0f, 0.0f, gfac, 0, false};
-    bool use_est = false;
+    bool use_est = false, few_levels = false;
     if (HOOK == HOOK_GRID) {
         const int levels = tab->levels;
+        // uniform-mass grid kernel (gate 1) and its general-mass stand-in (gate 2) are launched as a
+        // pair; the tables decide on the device which of the two does the work
+        const int ok = tab->uniform_ok;
+        if ((gate == 1 && !ok) || (gate == 2 && ok)) return;
+        // <= 32 levels: lanes mostly share records, the 16-byte record read broadcasts (one LDS access
+        // per pair).  More levels: random 16-byte reads saturate the LDS, two dependent 4-byte reads
+        // (threshold, then LUT value) are cheaper.
+        few_levels = levels <= NB_REC_LEVELS;
         for (int k = threadIdx.x; k <= NB_MAX_LUT; k += NB_BLOCK) {
             // binary search pads with +inf; the estimate path needs the NaN sentinel at thr[levels]
             s_thr[k] = (k <= levels) ? tab->thr[k] : __builtin_inff();
-            if (k < NB_MAX_LUT) s_lut[k] = (k < levels) ? tab->lut[k] : 0.0f;
+            // uniform masses: padding particles (r2 >= 1e36) are caught by one more "bin" of weight 0
+            if (UNIFORM && k == levels) s_thr[k] = 1e35f;
+            s_lut[k] = (k < levels) ? tab->lut[k] : 0.0f;
         }
         ga.degenerate = tab->degenerate != 0;
         ga.est_a = tab->est_a;
         ga.est_b = tab->est_b;
-        ga.lmax_bin = levels - 1;
+        ga.lmax_bin = UNIFORM ? levels : levels - 1;
         use_est = tab->use_est != 0;
         __syncthreads();
         for (int k = threadIdx.x; k < NB_MAX_LUT; k += NB_BLOCK)
-            s_rec[k] = make_float4(s_thr[k + 1], s_lut[k], s_lut[min(k + 1, NB_MAX_LUT - 1)], 0.0f);
+            s_rec[k] = make_float4(s_thr[k + 1], s_lut[k], s_lut[k + 1], 0.0f);
         __syncthreads();
     }
 
@@ -359,12 +371,15 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                     }
                     gj[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
                 }
-                if (HOOK == HOOK_GRID && use_est) {
-                    if (diag) sweep<T, D, R, true, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
-                    else sweep<T, D, R, false, UNIFORM, HOOK, true>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                if (HOOK == HOOK_GRID && use_est && few_levels) {
+                    if (diag) sweep<T, D, R, true, UNIFORM, HOOK, 1>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                    else sweep<T, D, R, false, UNIFORM, HOOK, 1>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                } else if (HOOK == HOOK_GRID && use_est) {
+                    if (diag) sweep<T, D, R, true, UNIFORM, HOOK, 2>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                    else sweep<T, D, R, false, UNIFORM, HOOK, 2>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
                 } else {
-                    if (diag) sweep<T, D, R, true, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
-                    else sweep<T, D, R, false, UNIFORM, HOOK, false>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                    if (diag) sweep<T, D, R, true, UNIFORM, HOOK, 0>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                    else sweep<T, D, R, false, UNIFORM, HOOK, 0>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r)
@@ -388,6 +403,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                 T v = s_aj[0][r][k][l];
 #pragma unroll
                 for (int w = 1; w < W; ++w) v += s_aj[w][r][k][l];
+                if (UNIFORM && HOOK == HOOK_GRID) v *= (T)gfac;      // gfac = the common mass here
                 colslab[((size_t)wk.col_ord * D + k) * np + (size_t)J * B + r * 64 + l] = v;
             }
         }
@@ -399,7 +415,9 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int k = 0; k < D; ++k) rowslab[((size_t)slot * D + k) * B + r * 64 + lane] = ai_sum[r][k];
+        for (int k = 0; k < D; ++k)
+            rowslab[((size_t)slot * D + k) * B + r * 64 + lane] =
+                (UNIFORM && HOOK == HOOK_GRID) ? ai_sum[r][k] * (double)gfac : ai_sum[r][k];
 }
 
 // Padding particles sit at `pad` in every coordinate (chosen by nb_launch_pack): r^2 stays finite and
@@ -603,14 +621,21 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
 
 template <typename T, int D, int R, int HOOK>
 hipError_t launch_sym_u(const T *packed, const SymWork *work, int nwork, double *rowslab, T *colslab, int np,
-                        int uniform, T eps2, const GridTables *tab, float gfac, hipStream_t st)
+                        int uniform, T eps2, const GridTables *tab, float gfac, hipStream_t st, float mass_value = 0.0f)
 {
-    if (uniform)
+    if (uniform && HOOK == HOOK_GRID) {
+        // uniform-mass grid kernel, valid only while the tables say so (GridTables::uniform_ok, known on the
+        // device only): launch it together with the general kernel, exactly one of the two does the work
         hipLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, packed, work,
-                           rowslab, colslab, np, eps2, tab, gfac);
+                           rowslab, colslab, np, eps2, tab, mass_value, 1);
+        hipLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, packed, work,
+                           rowslab, colslab, np, eps2, tab, gfac, 2);
+    } else if (uniform)
+        hipLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, packed, work,
+                           rowslab, colslab, np, eps2, tab, gfac, 0);
     else
         hipLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, packed, work,
-                           rowslab, colslab, np, eps2, tab, gfac);
+                           rowslab, colslab, np, eps2, tab, gfac, 0);
     return hipGetLastError();
 }
 
@@ -656,14 +681,14 @@ hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, in
 
 hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int nwork, double *rowslab,
                                    float *colslab, int np, int dim, int r, int uniform, int hook, float eps2,
-                                   const GridTables *tab, float G, hipStream_t st)
+                                   const GridTables *tab, float G, float mass_value, hipStream_t st)
 {
 #define NB_SYM32(DD, RR)                                                                                              \
     switch (hook) {                                                                                                   \
     case HOOK_NONE: return launch_sym_u<float, DD, RR, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st); \
     case HOOK_BF16: return launch_sym_u<float, DD, RR, HOOK_BF16>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st); \
     case HOOK_F16: return launch_sym_u<float, DD, RR, HOOK_F16>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st);   \
-    case HOOK_GRID: return launch_sym_u<float, DD, RR, HOOK_GRID>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st); \
+    case HOOK_GRID: return launch_sym_u<float, DD, RR, HOOK_GRID>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st, mass_value); \
     default: return hipErrorInvalidValue;                                                                             \
     }
     if (dim == 2 && r == 2) { NB_SYM32(2, 2) }

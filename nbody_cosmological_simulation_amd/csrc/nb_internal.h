@@ -10,6 +10,9 @@
 constexpr int NB_BLOCK = 256;   // 4 wavefronts of 64
 constexpr int NB_TJ = 256;      // sources staged in LDS per tile (one per thread)
 constexpr int NB_MAX_LUT = 256; // grid levels served by the LDS threshold table
+#ifndef NB_REC_LEVELS
+#define NB_REC_LEVELS 32         // up to this many levels the pair loop reads one 16-byte record per pair
+#endif
 
 // hooks compiled into the pair loop (quantization.py:21-71)
 enum { HOOK_NONE = 0, HOOK_BF16 = 1, HOOK_F16 = 2, HOOK_GRID = 3,
@@ -27,6 +30,8 @@ struct GridTables {
     int degenerate;          // 1: lmax-lmin < 1e-10 -> values pass through clamped
     int levels;
     unsigned int r2max_bits; // atomicMax target (positive floats order as unsigned ints)
+    int uniform_ok;          // 1: the uniform-mass grid kernel may run (estimate usable, r2max far below the
+                             //    padding distance, so "r2 >= 1e35" identifies padding particles)
 };
 
 // Scratch of the pruned max-r2 search (nb_force.hip "K2 with pruning").
@@ -71,7 +76,7 @@ hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, in
                                    hipStream_t st);
 hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int nwork, double *rowslab,
                                    float *colslab, int np, int dim, int r, int uniform, int hook, float eps2,
-                                   const GridTables *tab, float G, hipStream_t st);
+                                   const GridTables *tab, float G, float mass_value, hipStream_t st);
 hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int nwork, double *part, int np, int dim,
                                    int r, int is_f64, int f32_terms, int mass_f32, double eps2, hipStream_t st);
 hipError_t nb_launch_final_sum(const double *part, int count, double *out, hipStream_t st);
