@@ -187,7 +187,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2 rot1_f2(f2 v, int addr) { return f2{rot1<float>(v.x, addr), rot1<float>(v.y, addr)}; }
 
-template <int D, int R, bool DIAG, bool UNIFORM, int HOOK, bool EST>
+template <int D, int R, bool DIAG, bool UNIFORM, int HOOK, int EST>
 __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&gi)[R], f2 (&ai2)[R][D],
                                          f2 (&xj2)[R / 2][D], f2 (&gj2)[R / 2], f2 (&aj2)[R / 2][D], float eps2,
                                          int rot_addr, const GridArgs &ga, int nsteps)
@@ -210,9 +210,12 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                     if (ga.degenerate) {
                         w.x = inv_r3_sym((r2.x < 0.01f) ? 0.01f : r2.x, 1.5f, 0.0f) * ga.gfac;
                         w.y = inv_r3_sym((r2.y < 0.01f) ? 0.01f : r2.y, 1.5f, 0.0f) * ga.gfac;
-                    } else if (EST) {
+                    } else if (EST == 1) {
                         w.x = grid_w_estimate(ga.rec, r2.x, ga.est_a, ga.est_b, ga.lmax_bin - 1);
                         w.y = grid_w_estimate(ga.rec, r2.y, ga.est_a, ga.est_b, ga.lmax_bin - 1);
+                    } else if (EST == 2) {
+                        w.x = ga.lut[grid_bin_floor_estimate(ga.thr, r2.x, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
+                        w.y = ga.lut[grid_bin_floor_estimate(ga.thr, r2.y, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
                     } else {
                         w.x = ga.lut[grid_bin_lookup<NB_MAX_LUT>(ga.thr, r2.x)];
                         w.y = ga.lut[grid_bin_lookup<NB_MAX_LUT>(ga.thr, r2.y)];
@@ -325,9 +328,10 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
             for (int k = 0; k < D; ++k) aj[r][k] = (T)0;
         if (J >= I) {                                   // wave-uniform; tiles below the diagonal belong to other rows
             const bool diag = (J == I);
-            if constexpr (F32 && (R % 2 == 0) && HOOK != HOOK_GRID) {
-                // fp32 cast modes: source slots (2h, 2h+1) packed in float2 halves (sweep_pk).  The grid hook
-                // keeps the scalar loop: its per-component lookups do not pack and the packed form spills.
+            if constexpr (F32 && (R % 2 == 0) && (HOOK != HOOK_GRID || UNIFORM)) {
+                // fp32 modes: source slots (2h, 2h+1) packed in float2 halves (sweep_pk).  The general-mass
+                // grid kernel keeps the scalar loop (the packed form spills there); the uniform-mass one
+                // always has a usable estimate (GridTables::uniform_ok gates it).
                 f2 xj2[R / 2][D], gj2[R / 2], aj2[R / 2][D], ai2[R][D];
 #pragma unroll
                 for (int h = 0; h < R / 2; ++h) {
@@ -344,12 +348,15 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                 for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int k = 0; k < D; ++k) ai2[r][k] = f2{0.0f, 0.0f};
-                if (HOOK == HOOK_GRID && use_est) {
-                    if (diag) sweep_pk<D, R, true, UNIFORM, HOOK, true>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
-                    else sweep_pk<D, R, false, UNIFORM, HOOK, true>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                if (HOOK == HOOK_GRID && few_levels) {
+                    if (diag) sweep_pk<D, R, true, UNIFORM, HOOK, 1>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    else sweep_pk<D, R, false, UNIFORM, HOOK, 1>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                } else if (HOOK == HOOK_GRID) {
+                    if (diag) sweep_pk<D, R, true, UNIFORM, HOOK, 2>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    else sweep_pk<D, R, false, UNIFORM, HOOK, 2>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
                 } else {
-                    if (diag) sweep_pk<D, R, true, UNIFORM, HOOK, false>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
-                    else sweep_pk<D, R, false, UNIFORM, HOOK, false>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    if (diag) sweep_pk<D, R, true, UNIFORM, HOOK, 0>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    else sweep_pk<D, R, false, UNIFORM, HOOK, 0>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
                 }
 #pragma unroll
                 for (int h = 0; h < R / 2; ++h)
