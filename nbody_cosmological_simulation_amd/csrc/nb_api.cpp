@@ -140,7 +140,7 @@ struct nb_sim {
         bool enabled = false;
         int r = 2, tile_b = 128, tiles = 0, np = 0, nwork = 0, nslots = 0;
         SymWork *work = nullptr;
-        int *row_slot0 = nullptr, *row_nslots = nullptr, *col_base = nullptr, *col_count = nullptr;
+        int *row_slot0 = nullptr, *row_nslots = nullptr, *col_upto = nullptr;
         void *packed = nullptr, *colslab = nullptr;   // storage type of the state (fp32 or fp64)
         double *rowslab = nullptr;
     } sym;
@@ -259,15 +259,13 @@ int build_sym_plan(nb_sim *s)
         }
     }
     std::vector<SymWork> work;
-    std::vector<int> col_base(SR, 0), col_count(SR, 0);
+    std::vector<int> col_upto(sp.tiles, 0);   // slab entries [0, col_upto[J]) hold contributions to tile J
     int slots = 0, ncol = 0;
     for (int S = 0; S < SR; ++S) {
         if (ord[S] < 0) continue;
         const int j0 = 4 * S;
         const int nch = nch_of[S], nsp = split_of[S];
         const int per_row = nch * nsp;
-        col_base[S] = ncol;
-        col_count[S] = nsp;
         for (int w = 0; w < 4; ++w) { slot0[j0 + w] = slots + w * per_row; nslots[j0 + w] = per_row; }
         for (int ch = 0; ch < nch; ++ch)
             for (int q = 0; q < nsp; ++q) {
@@ -277,6 +275,14 @@ int build_sym_plan(nb_sim *s)
             }
         slots += 4 * per_row;
         ncol += nsp;
+    }
+    // slab entries are numbered in ascending super-row order, so the entries a tile needs -- those of the
+    // owned super-rows strictly above it, plus its own super-row when it is not the first tile of it --
+    // form a prefix of the index space
+    {
+        std::vector<int> first(SR + 1, 0);      // first[S] = entries of owned super-rows < S
+        for (int S = 0; S < SR; ++S) first[S + 1] = first[S] + (ord[S] >= 0 ? split_of[S] : 0);
+        for (int J = 0; J < sp.tiles; ++J) col_upto[J] = first[(J >> 2) + ((J & 3) ? 1 : 0)];
     }
     // whole sweeps first, pieces last (longest processing time first)
     std::stable_sort(work.begin(), work.end(), [](const SymWork &a, const SymWork &b) {
@@ -291,16 +297,14 @@ int build_sym_plan(nb_sim *s)
     HIPCHK(hipMalloc((void **)&sp.work, work.size() * sizeof(SymWork)));
     HIPCHK(hipMalloc((void **)&sp.row_slot0, sp.tiles * sizeof(int)));
     HIPCHK(hipMalloc((void **)&sp.row_nslots, sp.tiles * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&sp.col_base, SR * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&sp.col_count, SR * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&sp.col_upto, sp.tiles * sizeof(int)));
     HIPCHK(hipMalloc((void **)&sp.packed, (size_t)(c.dim + 1) * sp.np * el));
     HIPCHK(hipMalloc((void **)&sp.rowslab, (size_t)c.dim * sp.tile_b * sizeof(double) * (size_t)std::max(slots, 1)));
     HIPCHK(hipMalloc((void **)&sp.colslab, col_bytes));
     HIPCHK(hipMemcpy(sp.work, work.data(), work.size() * sizeof(SymWork), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(sp.row_slot0, slot0.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(sp.row_nslots, nslots.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp.col_base, col_base.data(), SR * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp.col_count, col_count.data(), SR * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp.col_upto, col_upto.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
     sp.enabled = true;
     return NB_OK;
 }
@@ -402,7 +406,7 @@ int acc_logical_dtype(const nb_sim *s)
     return promote(promote(promote(q, s->logical[2]), NB_F32), s->logical[0]);
 }
 
-int prof_begin(nb_sim *s, int *slot)
+int prof_begin(nb_sim *s, int *slot, bool record = true)
 {
     *slot = -1;
     if (!(s->cfg.flags & NB_FLAG_PROFILE)) return NB_OK;
@@ -424,8 +428,15 @@ int prof_begin(nb_sim *s, int *slot)
         s->prof_count = 0;
     }
     *slot = s->prof_count++;
-    HIPCHK(hipEventRecord(s->ev_start[*slot], s->stream));
+    if (record) HIPCHK(hipEventRecord(s->ev_start[*slot], s->stream));
     return NB_OK;
+}
+// events handed to a launcher that attaches them to the dispatch itself (no barrier packets on the stream)
+NbKernelEvents prof_events(nb_sim *s, int slot)
+{
+    NbKernelEvents ev;
+    if (slot >= 0) { ev.start = s->ev_start[slot]; ev.stop = s->ev_stop[slot]; }
+    return ev;
 }
 int prof_end(nb_sim *s, int slot)
 {
@@ -471,12 +482,11 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
             if (!packed_ready)
                 HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, 1, 0, 0.0, 0.0,
                                       c.G, pa_f32, s->stream));
-            if (int rc = prof_begin(s, &slot)) return rc;
+            if (int rc = prof_begin(s, &slot, false)) return rc;
             HIPCHK(nb_launch_force_sym_f64((const double *)sp.packed, sp.work, sp.nwork, sp.rowslab,
                                            (double *)sp.colslab, sp.np, c.dim, sp.r, s->mass_uniform, pa_f32,
-                                           c.softening_sq, s->stream));
+                                           c.softening_sq, s->stream, prof_events(s, slot)));
             s->last_kernel = "force_sym_kernel<double";
-            if (int rc = prof_end(s, slot)) return rc;
         } else {
             if (int rc = prof_begin(s, &slot)) return rc;
             HIPCHK(nb_launch_force_f64((const double *)s->pos, (const double *)s->mass, s->partial, s->geom, c.dim,
@@ -528,14 +538,13 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
             if (!packed_ready || hook == HOOK_GRID)
                 HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, 0, 0, 0.0, 0.0,
                                       gfac, 0, s->stream));
-            if (int rc = prof_begin(s, &slot)) return rc;
+            if (int rc = prof_begin(s, &slot, false)) return rc;
             // grid modes: the uniform kernel applies the common mass itself (reduce scale stays 1)
             HIPCHK(nb_launch_force_sym_f32((const float *)sp.packed, sp.work, sp.nwork, sp.rowslab,
                                            (float *)sp.colslab, sp.np, c.dim, sp.r,
                                            hook == HOOK_GRID ? s->mass_uniform : sym_uniform, hook, eps2, s->tab,
-                                           (float)c.G, (float)s->mass_value, s->stream));
+                                           (float)c.G, (float)s->mass_value, s->stream, prof_events(s, slot)));
             s->last_kernel = "force_sym_kernel<float";
-            if (int rc = prof_end(s, slot)) return rc;
         } else {
             if (int rc = prof_begin(s, &slot)) return rc;
             HIPCHK(nb_launch_force_f32((const float *)s->pos, (const float *)s->mass, s->partial, s->geom, c.dim, hook,
@@ -551,7 +560,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         // uniform-mass kernels leave out the mass factor: G*m in T arithmetic (fp32: (float)G * m)
         double scale = 1.0;
         if (sym_uniform) scale = s->is_f64 ? c.G * s->mass_value : (double)((float)c.G * (float)s->mass_value);
-        HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.col_base, sp.col_count,
+        HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.col_upto,
                                     sp.tile_b, c.n, sp.np, c.dim, s->is_f64, scale, s->acc, s->vel, half_dt, fuse_kick,
                                     s->stream));
     } else {
@@ -635,7 +644,7 @@ int nb_destroy(nb_sim *s)
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (void *p : {s->pos, s->vel, s->mass, s->acc, (void *)s->partial, s->staging, (void *)s->tab,
                     (void *)s->scratch, (void *)s->scalars, (void *)s->fbins, (void *)s->sym.work,
-                    (void *)s->sym.row_slot0, (void *)s->sym.row_nslots, (void *)s->sym.col_base, (void *)s->sym.col_count,
+                    (void *)s->sym.row_slot0, (void *)s->sym.row_nslots, (void *)s->sym.col_upto,
                     (void *)s->sym.packed, (void *)s->sym.rowslab, (void *)s->sym.colslab,
                     (void *)s->prune_cand, (void *)s->prune_rho, (void *)s->prune_state})
         if (p) (void)hipFree(p);

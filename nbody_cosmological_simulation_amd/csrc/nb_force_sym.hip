@@ -22,6 +22,8 @@
 //   slabs in a fixed order: no atomics, run-to-run bit-identical.
 #include "nb_device.h"
 
+#include <hip/hip_ext.h>
+
 #include <type_traits>
 
 namespace {
@@ -469,46 +471,39 @@ pack_kernel(T *__restrict__ pos, T *__restrict__ vel, const T *__restrict__ acc,
     }
 }
 
-// acc[p] = sum of the row slots of p's tile + sum over the super-rows at or above tile(p) of the column slabs,
-// always in the same order.  Block = 64 particles x 4 waves: wave g adds rows I = g, g+4, ...
-// (four loads in flight per lane), the four partial sums are combined in the order g = 0..3
-// through LDS -> still one fixed summation tree.  Optionally fuses the closing half kick
-// (simulation.py:141) and applies the uniform-mass factor.
+// acc[p] = sum of the row slots of p's tile + sum of the column-slab entries of the owned super-rows at or
+// above tile(p) (a prefix [0, col_upto[J]) of the slab index space), always in the same order.
+// Block = 64 particles x 16 waves: the items (row slots, then slab entries) are dealt over the waves
+// (item c to wave c mod 16, four independent loads in flight per lane), the 16 partial sums are
+// combined in wave order through LDS -> one fixed summation tree.  Optionally fuses the closing half
+// kick (simulation.py:141) and applies the uniform-mass factor.
+constexpr int NB_RED_WAVES = 16;
 template <typename T, int D>
-__global__ void __launch_bounds__(NB_BLOCK)
+__global__ void __launch_bounds__(64 * NB_RED_WAVES)
 reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ colslab,
                   const int *__restrict__ row_slot0, const int *__restrict__ row_nslots,
-                  const int *__restrict__ col_base, const int *__restrict__ col_count, int tile_b, int n, int np,
+                  const int *__restrict__ col_upto, int tile_b, int n, int np,
                   double scale, T *__restrict__ acc, T *__restrict__ vel, T half_dt, int do_kick)
 {
-    __shared__ double s_part[NB_BLOCK / 64][D][64];
+    __shared__ double s_part[NB_RED_WAVES][D][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + lane;
     const int pc = p < n ? p : n - 1;
-    const int J = pc / tile_b;
+    const int J = (blockIdx.x * 64) / tile_b;       // block-uniform: tile_b is a multiple of 64
+    const int s0 = row_slot0[J], ns = row_nslots[J], total = ns + col_upto[J];
+    const int off = blockIdx.x * 64 + lane - J * tile_b;
     double s[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) s[k] = 0.0;
-    {
-        // row slots of this tile (one per source chunk), dealt over the four waves like the slabs
-        const int s0 = row_slot0[J], ns = row_nslots[J];
-        const int off = pc - J * tile_b;
 #pragma unroll 4
-        for (int c = g; c < ns; c += NB_BLOCK / 64)
+    for (int c = g; c < total; c += NB_RED_WAVES) {
+        if (c < ns) {                               // wave-uniform
 #pragma unroll
             for (int k = 0; k < D; ++k) s[k] += rowslab[((size_t)(s0 + c) * D + k) * tile_b + off];
-    }
-    // column slabs: super-rows (four target tiles each) strictly above tile J, plus J's own
-    // super-row when J is not its first tile
-    const int SJ = J >> 2;
-    const int nsr = SJ + (((J & 3) > 0) ? 1 : 0);
-#pragma unroll 4
-    for (int SI = g; SI < nsr; SI += NB_BLOCK / 64) {
-        // col_count = 0: super-row owned by another rank; > 1: its sweeps were cut into pieces
-        const int base = col_base[SI], cnt = col_count[SI];
-        for (int q = 0; q < cnt; ++q)
+        } else {
 #pragma unroll
-            for (int k = 0; k < D; ++k) s[k] += (double)colslab[((size_t)(base + q) * D + k) * np + pc];
+            for (int k = 0; k < D; ++k) s[k] += (double)colslab[((size_t)(c - ns) * D + k) * np + pc];
+        }
     }
 #pragma unroll
     for (int k = 0; k < D; ++k) s_part[g][k][lane] = s[k];
@@ -518,7 +513,7 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
         for (int k = 0; k < D; ++k) {
             double t = s_part[0][k][lane];
 #pragma unroll
-            for (int w = 1; w < NB_BLOCK / 64; ++w) t += s_part[w][k][lane];
+            for (int w = 1; w < NB_RED_WAVES; ++w) t += s_part[w][k][lane];
             const size_t idx = (size_t)p * D + k;
             const T a = (T)(t * scale);            // scale = mass factor of the uniform kernel, else 1
             acc[idx] = a;
@@ -628,21 +623,22 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
 
 template <typename T, int D, int R, int HOOK>
 hipError_t launch_sym_u(const T *packed, const SymWork *work, int nwork, double *rowslab, T *colslab, int np,
-                        int uniform, T eps2, const GridTables *tab, float gfac, hipStream_t st, float mass_value = 0.0f)
+                        int uniform, T eps2, const GridTables *tab, float gfac, hipStream_t st, NbKernelEvents ev,
+                        float mass_value = 0.0f)
 {
     if (uniform && HOOK == HOOK_GRID) {
         // uniform-mass grid kernel, valid only while the tables say so (GridTables::uniform_ok, known on the
         // device only): launch it together with the general kernel, exactly one of the two does the work
-        hipLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, packed, work,
-                           rowslab, colslab, np, eps2, tab, mass_value, 1);
-        hipLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, packed, work,
-                           rowslab, colslab, np, eps2, tab, gfac, 2);
+        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
+                              nullptr, 0, packed, work, rowslab, colslab, np, eps2, tab, mass_value, 1);
+        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, nullptr,
+                              ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 2);
     } else if (uniform)
-        hipLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, packed, work,
-                           rowslab, colslab, np, eps2, tab, gfac, 0);
+        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
+                              ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 0);
     else
-        hipLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, packed, work,
-                           rowslab, colslab, np, eps2, tab, gfac, 0);
+        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
+                              ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 0);
     return hipGetLastError();
 }
 
@@ -670,32 +666,32 @@ hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mas
 
 hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, int nwork, double *rowslab,
                                    double *colslab, int np, int dim, int r, int uniform, int pa_f32, double eps2,
-                                   hipStream_t st)
+                                   hipStream_t st, NbKernelEvents ev)
 {
     if (pa_f32) {   // first evaluation on fp32-typed positions: default tile shapes only
         const float e32 = (float)eps2;
-        if (dim == 2 && r == 4) return launch_sym_u<double, 2, 4, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st);
-        if (dim == 3 && r == 2) return launch_sym_u<double, 3, 2, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st);
+        if (dim == 2 && r == 4) return launch_sym_u<double, 2, 4, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st, ev);
+        if (dim == 3 && r == 2) return launch_sym_u<double, 3, 2, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st, ev);
         return hipErrorInvalidValue;
     }
-    if (dim == 2 && r == 1) return launch_sym_u<double, 2, 1, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st);
-    if (dim == 2 && r == 2) return launch_sym_u<double, 2, 2, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st);
-    if (dim == 2 && r == 4) return launch_sym_u<double, 2, 4, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st);
-    if (dim == 3 && r == 1) return launch_sym_u<double, 3, 1, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st);
-    if (dim == 3 && r == 2) return launch_sym_u<double, 3, 2, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st);
+    if (dim == 2 && r == 1) return launch_sym_u<double, 2, 1, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st, ev);
+    if (dim == 2 && r == 2) return launch_sym_u<double, 2, 2, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st, ev);
+    if (dim == 2 && r == 4) return launch_sym_u<double, 2, 4, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st, ev);
+    if (dim == 3 && r == 1) return launch_sym_u<double, 3, 1, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st, ev);
+    if (dim == 3 && r == 2) return launch_sym_u<double, 3, 2, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st, ev);
     return hipErrorInvalidValue;
 }
 
 hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int nwork, double *rowslab,
                                    float *colslab, int np, int dim, int r, int uniform, int hook, float eps2,
-                                   const GridTables *tab, float G, float mass_value, hipStream_t st)
+                                   const GridTables *tab, float G, float mass_value, hipStream_t st, NbKernelEvents ev)
 {
 #define NB_SYM32(DD, RR)                                                                                              \
     switch (hook) {                                                                                                   \
-    case HOOK_NONE: return launch_sym_u<float, DD, RR, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st); \
-    case HOOK_BF16: return launch_sym_u<float, DD, RR, HOOK_BF16>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st); \
-    case HOOK_F16: return launch_sym_u<float, DD, RR, HOOK_F16>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st);   \
-    case HOOK_GRID: return launch_sym_u<float, DD, RR, HOOK_GRID>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st, mass_value); \
+    case HOOK_NONE: return launch_sym_u<float, DD, RR, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st, ev); \
+    case HOOK_BF16: return launch_sym_u<float, DD, RR, HOOK_BF16>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st, ev); \
+    case HOOK_F16: return launch_sym_u<float, DD, RR, HOOK_F16>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st, ev);   \
+    case HOOK_GRID: return launch_sym_u<float, DD, RR, HOOK_GRID>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st, ev, mass_value); \
     default: return hipErrorInvalidValue;                                                                             \
     }
     if (dim == 2 && r == 2) { NB_SYM32(2, 2) }
@@ -728,14 +724,14 @@ hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int 
 }
 
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
-                                const int *row_nslots, const int *col_base, const int *col_count, int tile_b, int n,
+                                const int *row_nslots, const int *col_upto, int tile_b, int n,
                                 int np, int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
                                 int do_kick, hipStream_t st)
 {
     const int grid = (n + 63) / 64;
 #define NB_RED(TT, DD) \
-    hipLaunchKernelGGL((reduce_sym_kernel<TT, DD>), dim3(grid), dim3(NB_BLOCK), 0, st, rowslab, (const TT *)colslab, \
-                       row_slot0, row_nslots, col_base, col_count, tile_b, n, np, scale, (TT *)acc, (TT *)vel, (TT)half_dt, do_kick)
+    hipLaunchKernelGGL((reduce_sym_kernel<TT, DD>), dim3(grid), dim3(64 * NB_RED_WAVES), 0, st, rowslab, (const TT *)colslab, \
+                       row_slot0, row_nslots, col_upto, tile_b, n, np, scale, (TT *)acc, (TT *)vel, (TT)half_dt, do_kick)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64) { if (dim == 2) NB_RED(double, 2); else NB_RED(double, 3); }
     else        { if (dim == 2) NB_RED(float, 2); else NB_RED(float, 3); }

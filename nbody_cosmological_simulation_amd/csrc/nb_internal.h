@@ -67,21 +67,28 @@ struct SymWork {
 };
 
 // pack positions + mass factors into padded component arrays; kick != 0 fuses the opening
+// Optional timing events of a launch: attached to the dispatch itself (hipExtLaunchKernelGGL), so the
+// kernel's own start / end timestamps are taken without barrier packets around it on the stream.
+struct NbKernelEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
 // kick + drift of a step (simulation.py:132,135)
 hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mass, void *packed, int n, int np,
                           int dim, int is_f64, int kick, double half_dt, double dt, double gfac, int f32_pairs,
                           hipStream_t st);
 hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, int nwork, double *rowslab,
                                    double *colslab, int np, int dim, int r, int uniform, int pa_f32, double eps2,
-                                   hipStream_t st);
+                                   hipStream_t st, NbKernelEvents ev = {});
 hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int nwork, double *rowslab,
                                    float *colslab, int np, int dim, int r, int uniform, int hook, float eps2,
-                                   const GridTables *tab, float G, float mass_value, hipStream_t st);
+                                   const GridTables *tab, float G, float mass_value, hipStream_t st,
+                                   NbKernelEvents ev = {});
 hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int nwork, double *part, int np, int dim,
                                    int r, int is_f64, int f32_terms, int mass_f32, double eps2, hipStream_t st);
 hipError_t nb_launch_final_sum(const double *part, int count, double *out, hipStream_t st);
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
-                                const int *row_nslots, const int *col_base, const int *col_count, int tile_b, int n,
+                                const int *row_nslots, const int *col_upto, int tile_b, int n,
                                 int np, int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
                                 int do_kick, hipStream_t st);
 

@@ -324,6 +324,13 @@ class GalaxySimulation:
     def synchronize(self):
         N.check(N.lib().nb_synchronize(self._handle))
 
+    def spin_up(self, evaluations: int):
+        """Re-evaluate the forces `evaluations` times without touching the state (the result is
+        bit-identical every time): lets the GPU reach its sustained clock before a timed region."""
+        self._flush(("positions", "masses"))
+        for _ in range(max(0, int(evaluations))):
+            N.check(N.lib().nb_compute_accelerations(self._handle))
+
     def kernel_time(self):
         """(total_ms, launches) of the force kernel since the last call (needs profile=True)."""
         ms, n = C.c_double(), C.c_int32()
