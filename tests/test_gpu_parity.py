@@ -876,3 +876,38 @@ def test_half_precision_state_in_float64_mode(nb, name, code):
     assert sim.positions.dtype == torch.float64 and sim.velocities.dtype == torch.float64
     assert relerr(sim.positions.numpy(), ref.positions) < 1e-13
     assert relerr(sim.velocities.numpy(), ref.velocities) < 1e-12
+
+
+@pytest.mark.parametrize("mode", ["int8_sim", "int4_sim", "custom"])
+@pytest.mark.parametrize("masses", ["uniform", "mixed"])
+def test_symmetric_grid_kernel_pair_selection(nb, monkeypatch, mode, masses):
+    """Grid modes on the pair-symmetric path launch the uniform-mass kernel and the general kernel as a pair
+    and let the device tables pick one (GridTables::uniform_ok).  Clouds that flip the choice -- ordinary,
+    a narrow grid (no usable estimate), all particles coincident (degenerate grid), a NaN coordinate -- must
+    match the oracle either way: accelerations before force quantisation, lmax and every distance bin."""
+    from oracle import oracle as O
+    monkeypatch.setenv("NB_SYM", "1")
+    rng = np.random.default_rng(23)
+    n = 700                                   # three tiles of 256: diagonal, off-diagonal and padded work
+    clouds = {
+        "ordinary": (rng.standard_normal((n, 2)) * 3).astype(np.float32),
+        "narrow": (rng.standard_normal((n, 2)) * 0.0002).astype(np.float32),   # a = ln2 (L-1)/range > 1e4
+        "coincident": np.full((n, 2), 0.25, np.float32),
+    }
+    mass = np.full(n, 0.75, np.float32) if masses == "uniform" else rng.uniform(0.5, 2.0, n).astype(np.float32)
+    for name, pos in clouds.items():
+        sim = nb.GalaxySimulation(T(pos), torch.zeros(n, 2), T(mass), precision_mode=nb.PrecisionMode(mode))
+        assert sim.force_kernel_name().startswith("force_sym_kernel<float"), name
+        ref, dbg = O.accelerations(pos, mass, mode, debug=True)
+        got = sim.quant_debug(bins=True)
+        assert np.float32(got["lmax"]) == np.float32(dbg["lmax"]), name
+        assert np.array_equal(got["d2bins"], dbg["d2bins"]), name
+        acc = sim.accelerations.numpy()
+        scale = np.abs(ref).max() + 1e-30
+        # force quantisation (int8/int4) snaps to a grid of the summed forces: compare in grid steps
+        tol = 2e-6 if mode == "custom" else 1.01 * (dbg["fmax"] - dbg["fmin"]) / ((256 if mode == "int8_sim" else 16) - 1) / scale
+        assert np.abs(acc - ref).max() / scale <= max(tol, 2e-6), (name, np.abs(acc - ref).max() / scale)
+    pos = clouds["ordinary"].copy()
+    pos[5, 0] = np.nan
+    sim = nb.GalaxySimulation(T(pos), torch.zeros(n, 2), T(mass), precision_mode=nb.PrecisionMode(mode))
+    assert torch.isnan(sim.accelerations).all()
