@@ -205,6 +205,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and is64:
             out["cpu_baseline"] = cpu_baseline(pos, vel, mass, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+    sim.close()                       # communicator down on every rank before the process group goes
     if launched:
         dist.barrier()
         dist.destroy_process_group()

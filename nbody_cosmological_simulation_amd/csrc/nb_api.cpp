@@ -177,7 +177,10 @@ void compute_geometry(nb_sim *s)
     g.n = n;
     g.j_begin = (int)((int64_t)s->cfg.rank * n / s->cfg.nranks);
     g.j_end = (int)((int64_t)(s->cfg.rank + 1) * n / s->cfg.nranks);
-    g.r = 2;
+    // targets per thread of the one-sided fp64 kernel.  Small systems are parallelism-bound, not
+    // throughput-bound: R = 1 doubles the workgroups (N = 1024: 27.8 -> 17.6 us per step, N = 4096:
+    // 32.5 -> 22.6 us)
+    g.r = (n <= 8192) ? 1 : 2;
     if (const char *e = getenv("NB_R")) {           // tuning knob: targets per thread (1, 2 or 4)
         const int r = atoi(e);
         if (r == 1 || r == 2 || r == 4) g.r = r;
@@ -202,7 +205,11 @@ int build_sym_plan(nb_sim *s)
     auto &sp = s->sym;
     sp.enabled = false;
     const nb_config &c = s->cfg;
-    int want = (c.n >= 4096) ? 1 : 0;
+    // Below ~10 k particles the pair-symmetric kernel has too few work items to fill the chip (one
+    // 64-step sweep per wave is its floor: ~53 us per step at any N <= 8192) and the one-sided LDS kernel
+    // wins (measured fp64, us per step, one-sided / symmetric: N = 4096 22.6 / 53.3, 8192 48.7 / 54.7,
+    // 12288 90.6 / 83.4, 16384 149 / 118).
+    int want = (c.n > 8192) ? 1 : 0;
     if (const char *e = getenv("NB_SYM")) want = atoi(e);
     if (!want || (c.flags & NB_FLAG_NO_COMM)) return NB_OK;
     if (s->is_f64 && c.mode != NB_FLOAT64) return NB_OK;    // fp64 state under a cast mode: one-sided kernel

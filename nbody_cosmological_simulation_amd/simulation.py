@@ -133,7 +133,10 @@ class GalaxySimulation:
         self.tick += 1
 
     # ------------------------------------------------------------------ native plumbing
-    def __del__(self):
+    def close(self):
+        """Release the native handle (device buffers, stream, RCCL communicator) now instead of at garbage
+        collection.  Multi-GPU: collective -- every rank closes its simulations in the same order, before
+        torch.distributed is torn down."""
         h = getattr(self, "_handle", None)
         if h is not None and h.value:
             try:
@@ -141,6 +144,9 @@ class GalaxySimulation:
             except Exception:
                 pass
             h.value = None
+
+    def __del__(self):
+        self.close()
 
     def _upload(self, name, tensor):
         self._serial += 1

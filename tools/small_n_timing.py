@@ -1,10 +1,14 @@
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import nbody_cosmological_simulation_amd as nb
 from nbody_cosmological_simulation_amd import galaxy
-for n in (1024, 4096, 16384):
+ns = [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384]
+mode = nb.get_mode_from_string(__import__("os").environ.get("MODE", "float64"))
+for n in ns:
     pos, vel, mass = galaxy.create_disk_galaxy(n, seed=42, device="cpu")
-    sim = nb.GalaxySimulation(pos.cuda(), vel.cuda(), mass.cuda(), precision_mode=nb.PrecisionMode.FLOAT64)
-    sim.run(20); sim.synchronize()
-    t = time.perf_counter(); sim.run(200); sim.synchronize(); dt = time.perf_counter() - t
-    print(f"N={n}: {dt/200*1e6:.1f} us/step, {n*200/dt:.3e} particle-steps/s, kernel {sim.force_kernel_name()}")
+    sim = nb.GalaxySimulation(pos.cuda(), vel.cuda(), mass.cuda(), precision_mode=mode)
+    t = time.perf_counter()
+    while time.perf_counter() - t < 0.1:          # ~100 ms of steps: past the clock ramp
+        sim.run(50); sim.synchronize()
+    t = time.perf_counter(); sim.run(1000); sim.synchronize(); dt = time.perf_counter() - t
+    print(f"N={n}: {dt/1000*1e6:.1f} us/step, {n*1000/dt:.3e} particle-steps/s, kernel {sim.force_kernel_name()}")
