@@ -191,7 +191,10 @@ def main():
             "pair_interactions_per_s": float(n) * n * args.steps / elapsed,
             "energy_drift_rel": (e1 - e0) / abs(e0),
             "roofline": {
-                "bound": "valu", "bound_note": "fp64 vector ALU (compute-bound; HBM traffic is O(N) per step)",
+                "bound": "mfma",
+                "bound_note": "compute-bound: priced against the dense fp64 (fp32 modes: fp32) MFMA peak, which on MI355X "
+                              "equals the vector-ALU peak the kernel actually issues on (the pair loop is VALU code: "
+                              "contraction dimension D = 2, DESIGN.md section 3); HBM traffic is O(N) per step",
                 "kernel": kernel_name,
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "avg_launch_ms": avg_ms, "launches": launches, "timing": timing,
