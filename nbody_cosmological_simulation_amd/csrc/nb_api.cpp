@@ -211,7 +211,9 @@ int build_sym_plan(nb_sim *s)
     // 12288 90.6 / 83.4, 16384 149 / 118).
     int want = (c.n > 8192) ? 1 : 0;
     if (const char *e = getenv("NB_SYM")) want = atoi(e);
-    if (!want || (c.flags & NB_FLAG_NO_COMM)) return NB_OK;
+    // comm-less shards (NB_FLAG_NO_COMM) use the one-sided kernel unless NB_SYM=2 asks for the symmetric
+    // plan of their rank (tests: the partial sums of all ranks' plans must add up to the full result)
+    if (!want || ((c.flags & NB_FLAG_NO_COMM) && want < 2)) return NB_OK;
     if (s->is_f64 && c.mode != NB_FLOAT64) return NB_OK;    // fp64 state under a cast mode: one-sided kernel
     sp.r = (c.dim == 2) ? 4 : 2;       // measured on MI355X, N=65536: R=1 3.39 ms, R=2 1.87 ms, R=4 1.47 ms
     if (const char *e = getenv("NB_SYM_R")) {

@@ -912,3 +912,44 @@ def test_symmetric_grid_kernel_pair_selection(nb, monkeypatch, mode, masses):
     pos[5, 0] = np.nan
     sim = nb.GalaxySimulation(T(pos), torch.zeros(n, 2), T(mass), precision_mode=nb.PrecisionMode(mode))
     assert torch.isnan(sim.accelerations).all()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_symmetric_plan_of_every_rank_adds_up(nb, monkeypatch, world):
+    """Multi-GPU by construction: the pair-symmetric work lists the P ranks would run (snake-dealt super-rows,
+    tail smoothing, per-rank slab prefixes) are executed one after the other on this GPU as comm-less shards
+    (NB_SYM=2); what RCCL would all-reduce -- the partial forces and the partial potential energies -- must
+    add up to the single-GPU result.  fp64 (fp64- and fp32-typed positions), fp32 and a grid mode; D = 2 and 3."""
+    from nbody_cosmological_simulation_amd import galaxy
+    monkeypatch.setenv("NB_SYM", "2")
+    rng = np.random.default_rng(world)
+    cases = []
+    p2, v2, m2 = galaxy.create_disk_galaxy(9000, seed=world, device="cpu")
+    cases.append(("f64 D2", p2.double(), v2.double(), m2.double(), nb.PrecisionMode.FLOAT64, 1e-13))
+    cases.append(("f64-mode fp32-typed D2", p2, v2, m2, nb.PrecisionMode.FLOAT64, 1e-13))
+    cases.append(("f32 D2", p2, v2, m2 * torch.from_numpy(rng.uniform(0.5, 1.5, 9000).astype(np.float32)),
+                  nb.PrecisionMode.FLOAT32, 2e-6))
+    cases.append(("custom D2", p2, v2, m2, nb.PrecisionMode.CUSTOM, 2e-6))
+    p3 = torch.from_numpy((rng.standard_normal((5000, 3)) * 4).astype(np.float32))
+    cases.append(("f64 D3", p3.double(), torch.zeros(5000, 3, dtype=torch.float64), torch.ones(5000, dtype=torch.float64),
+                  nb.PrecisionMode.FLOAT64, 1e-13))
+    if world == 8:      # the driver's scaling run: BASELINE config 2 on 8 ranks (tail-smoothed plans)
+        pb, vb, mb = galaxy.create_disk_galaxy(65536, seed=42, device="cpu")
+        cases.append(("f64 N=65536", pb.double(), vb.double(), mb.double(), nb.PrecisionMode.FLOAT64, 1e-13))
+    for name, pos, vel, mass, mode, tol in cases:
+        full = nb.GalaxySimulation(pos, vel, mass, precision_mode=mode)
+        assert full.force_kernel_name().startswith("force_sym_kernel"), name
+        acc = full.accelerations.numpy().astype(np.float64)
+        pe = full.get_potential_energy()
+        parts, pes = [], []
+        for r in range(world):
+            s = nb.GalaxySimulation(pos, vel, mass, precision_mode=mode, shard=(r, world))
+            assert s.force_kernel_name().startswith("force_sym_kernel"), (name, r)
+            parts.append(s.accelerations.numpy().astype(np.float64))
+            pes.append(s.get_potential_energy())
+            s.close()
+        assert relerr(sum(parts), acc) < tol, (name, relerr(sum(parts), acc))
+        # energies of fp32-typed state are fp32 numbers (each shard's partial is rounded on the way out here;
+        # the real multi-GPU path all-reduces the fp64 partials before that rounding)
+        pe_tol = 1e-12 if pos.dtype == torch.float64 else 2e-6
+        assert abs(sum(pes) - pe) <= pe_tol * abs(pe), (name, sum(pes), pe)
