@@ -19,17 +19,23 @@ constexpr int UNROLL = 8;
 
 // Each op kernel keeps UNROLL independent chains per lane so issue rate, not latency, is measured.
 enum { OP_FMA64, OP_MUL64, OP_ADD64, OP_RSQ64, OP_RCP64, OP_SQRT64, OP_CVT64_32, OP_CVT32_64, OP_FMA32, OP_RSQ32,
-       OP_MIX_PAIR, OP_NOPS };
+       OP_MFMA64_4, OP_MFMA64_4_FMA6, OP_FMA64_X6, OP_MIX_PAIR, OP_NOPS };
 const char *OP_NAMES[] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rsq_f64", "v_rcp_f64", "v_sqrt_f64",
-                          "v_cvt_f32_f64", "v_cvt_f64_f32", "v_fma_f32", "v_rsq_f32", "pair_body_f64"};
+                          "v_cvt_f32_f64", "v_cvt_f64_f32", "v_fma_f32", "v_rsq_f32",
+                          "mfma_f64_4x4x4", "mfma4x4x4+6fma", "6 x v_fma_f64", "pair_body_f64"};
 
 template <int OP>
 __global__ void __launch_bounds__(256) op_kernel(double *out, double seed)
 {
-    double a[UNROLL];
+    double a[UNROLL], g[UNROLL][6];
     float f[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) { a[u] = seed + threadIdx.x * 1e-3 + u; f[u] = (float)a[u]; }
+    for (int u = 0; u < UNROLL; ++u) {
+        a[u] = seed + threadIdx.x * 1e-3 + u;
+        f[u] = (float)a[u];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g[u][k] = a[u] + k;
+    }
     const double b = 1.0000001, c = 1e-9;
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
@@ -44,11 +50,22 @@ __global__ void __launch_bounds__(256) op_kernel(double *out, double seed)
             if (OP == OP_CVT32_64) { a[u] = (double)f[u]; asm volatile("" : "+v"(a[u])); }
             if (OP == OP_FMA32) f[u] = __builtin_fmaf(f[u], 1.0000001f, 1e-9f);
             if (OP == OP_RSQ32) f[u] = __builtin_amdgcn_rsqf(f[u]);
+            // matrix pipe: does v_mfma_f64_4x4x4_4b overlap with VALU FMAs of the same and of other waves?
+            if (OP == OP_MFMA64_4 || OP == OP_MFMA64_4_FMA6) a[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(b, c, a[u], 0, 0, 0);
+            if (OP == OP_MFMA64_4_FMA6 || OP == OP_FMA64_X6) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) g[u][k] = __builtin_fma(g[u][k], b, c);
+            }
         }
     }
     double s = 0;
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) s += a[u] + f[u];
+    for (int u = 0; u < UNROLL; ++u) {
+        s += a[u] + f[u];
+        if (OP == OP_MFMA64_4_FMA6 || OP == OP_FMA64_X6)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s += g[u][k];
+    }
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -123,6 +140,10 @@ int main()
     const int blocks_per_cu[] = {1, 2, 4};
     CHECK(hipMalloc(&out, sizeof(double) * 256 * cus * 8));
 
+    // ~150 ms of fp64 FMAs first: the chip needs tens of ms to reach its sustained clock
+    for (int r = 0; r < 300; ++r) hipLaunchKernelGGL(op_kernel<OP_FMA64>, dim3(cus * 4), dim3(256), 0, 0, out, 1.5);
+    CHECK(hipDeviceSynchronize());
+
     printf("\n# issue rate: cycles per wave64 instruction per SIMD (at nominal clock), by waves/SIMD\n");
     printf("%-16s %10s %10s %10s\n", "op", "1 wave", "2 waves", "4 waves");
     for (int op = 0; op <= OP_MIX_PAIR; ++op) {
@@ -134,6 +155,7 @@ int main()
 #define CASE(O) case O: hipLaunchKernelGGL(op_kernel<O>, dim3(grid), dim3(256), 0, 0, out, 1.5); break;
                     CASE(OP_FMA64) CASE(OP_MUL64) CASE(OP_ADD64) CASE(OP_RSQ64) CASE(OP_RCP64) CASE(OP_SQRT64)
                     CASE(OP_CVT64_32) CASE(OP_CVT32_64) CASE(OP_FMA32) CASE(OP_RSQ32)
+                    CASE(OP_MFMA64_4) CASE(OP_MFMA64_4_FMA6) CASE(OP_FMA64_X6)
 #undef CASE
                 case OP_MIX_PAIR: hipLaunchKernelGGL(pair_kernel, dim3(grid), dim3(256), 0, 0, out, 1.5); break;
                 }
