@@ -456,7 +456,8 @@ int prof_end(nb_sim *s, int slot)
 // one evaluation of simulation.py:74-118; optionally followed by the closing half kick (:141)
 // defer_kick: the caller will apply the closing half kick itself (fused into the next step's
 // opening launch) when this evaluation cannot fuse it into its reduction.
-int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_kick = nullptr)
+int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_kick = nullptr,
+               bool *open_next = nullptr)
 {
     if (!s->have_pos || !s->have_mass) return fail(NB_ERR_INVALID, "positions and masses must be set first");
     const nb_config &c = s->cfg;
@@ -518,8 +519,11 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
             if (L > NB_MAX_LUT || L < 2)
                 return fail(NB_ERR_UNSUPPORTED, "grid levels must be in [2, %d] on the fused path (got %d)",
                             NB_MAX_LUT, L);
-            HIPCHK(hipMemsetAsync(&s->tab->r2max_bits, 0, sizeof(unsigned int), s->stream));
-            if (!getenv("NB_NO_PRUNE")) {
+            // tab->r2max_bits is 0 here: zeroed at creation, put back by grid_tables_kernel after each use.
+            // Small systems scan all pairs in one launch; the pruned search (six launches, O(N) + candidates^2)
+            // pays off above that.
+            const bool prune = !getenv("NB_NO_PRUNE") && c.n > 8192;
+            if (prune) {
                 // every rank finds the global maximum itself: O(N) + (outer candidates)^2, no collective
                 HIPCHK(nb_launch_r2max_pruned((const float *)s->pos, c.n, c.dim, eps2, s->prune_cand, s->prune_rho,
                                               s->prune_state, s->tab, s->stream));
@@ -535,8 +539,8 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
                     NCCLCHK(g_rccl.AllReduce(&s->tab->r2max_bits, &s->tab->r2max_bits, 1, ncclUint32, ncclMax, s->comm,
                                              s->stream));
             }
-            HIPCHK(nb_launch_grid_tables(s->tab, L, (float)c.G, eps2, 0.01f,
-                                         getenv("NB_NO_PRUNE") ? nullptr : s->prune_state, s->stream));
+            HIPCHK(nb_launch_grid_tables(s->tab, L, (float)c.G, eps2, 0.01f, prune ? s->prune_state : nullptr,
+                                         s->stream));
         }
         used_sym = s->sym.enabled && pa == NB_F32;
         if (used_sym) {
@@ -564,6 +568,8 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
     }
 
     const bool fuse_kick = do_kick && !multi && !fq;
+    const bool want_open = do_kick && open_next && *open_next;   // nb_step asks: may this evaluation open the next step?
+    bool opened = false;
     if (used_sym) {
         const auto &sp = s->sym;
         // uniform-mass kernels leave out the mass factor: G*m in T arithmetic (fp32: (float)G * m)
@@ -573,18 +579,29 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
                                     sp.tile_b, c.n, sp.np, c.dim, s->is_f64, scale, s->acc, s->vel, half_dt, fuse_kick,
                                     s->stream));
     } else {
-        HIPCHK(nb_launch_reduce(s->partial, s->geom.nchunks, cnt, s->acc, s->is_f64, s->vel, half_dt, fuse_kick,
-                                s->stream));
+        // one-sided path inside nb_step: the reduction can also open the next step (one launch fewer per step,
+        // which is what small systems are bound by)
+        const bool open = fuse_kick && want_open;
+        HIPCHK(nb_launch_reduce(s->partial, s->geom.nchunks, cnt, s->acc, s->is_f64, s->vel, half_dt,
+                                open ? 2 : (fuse_kick ? 1 : 0), s->pos, c.dt, s->stream));
+        opened = open;
     }
     if (multi)
         NCCLCHK(g_rccl.AllReduce(s->acc, s->acc, (size_t)cnt, s->is_f64 ? ncclDouble : ncclFloat, ncclSum, s->comm,
                                  s->stream));
+    bool kicked = fuse_kick;
     if (fq) {
-        HIPCHK(nb_launch_minmax_generic(s->acc, 0, cnt, 0, 0.0, s->scalars, s->scalars + 8, s->stream));
-        HIPCHK(nb_launch_force_quant_bins((const float *)s->acc, (float *)s->acc, cnt, mode_levels(c), s->scalars,
-                                          s->fbins, s->stream));
+        // min/max of the summed forces, then quantisation with the closing kick (and, inside nb_step, the next
+        // step's opening kick + drift) in the same launch
+        const bool open = want_open;
+        HIPCHK(nb_launch_force_quant_step((float *)s->acc, cnt, mode_levels(c), s->scalars, s->scalars + 8, s->fbins,
+                                          (float *)s->vel, (float *)s->pos, half_dt, c.dt, do_kick ? (open ? 2 : 1) : 0,
+                                          s->stream));
+        kicked = do_kick;
+        opened = open;
     }
-    if (do_kick && !fuse_kick) {
+    if (open_next) *open_next = opened;
+    if (do_kick && !kicked) {
         if (defer_kick) *defer_kick = true;
         else HIPCHK(nb_launch_axpy(s->vel, s->acc, half_dt, cnt, s->is_f64, s->stream));
     }
@@ -772,12 +789,16 @@ int nb_step(nb_sim *s, int32_t nsteps)
     if (!s->have_acc) return fail(NB_ERR_INVALID, "no accelerations yet: call nb_compute_accelerations first");
     DeviceGuard guard(s->cfg.device);
     bool pending_close = false;     // closing kick of the previous step still to be applied
+    bool opened = false;            // the previous step's reduction already did this step's opening kick + drift
     for (int t = 0; t < nsteps; ++t) {
         // opening kick + drift; on the pair-symmetric path the repack rides in the same launch
         const int sdt = s->is_f64 ? NB_F64 : NB_F32;
         const bool fuse_pack = s->sym.enabled && s->logical[0] == sdt && s->logical[1] == sdt &&
                                s->logical[3] == sdt && !grid_mode(s->cfg.mode);
-        if (fuse_pack) {
+        const bool uniform_dt = s->logical[0] == sdt && s->logical[1] == sdt && s->logical[3] == sdt;
+        if (opened) {
+            // nothing to launch: positions and velocities were advanced by the previous reduction
+        } else if (fuse_pack) {
             HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, s->sym.packed, s->cfg.n, s->sym.np, s->cfg.dim,
                                   s->is_f64, pending_close ? 2 : 1, s->cfg.dt / 2, s->cfg.dt,
                                   s->is_f64 ? s->cfg.G : (double)(float)s->cfg.G, 0, s->stream));
@@ -791,7 +812,8 @@ int nb_step(nb_sim *s, int32_t nsteps)
         // a closing kick that cannot ride in the reduction (RCCL all-reduce / force quantisation in
         // between) is folded into the next step's opening launch when there is one
         const bool may_defer = (t + 1 < nsteps) && fuse_pack;
-        if (int rc = force_eval(s, true, fuse_pack, may_defer ? &pending_close : nullptr)) return rc;
+        opened = (t + 1 < nsteps) && uniform_dt && (!s->sym.enabled || force_quant_mode(s->cfg));   // request; force_eval answers
+        if (int rc = force_eval(s, true, fuse_pack, may_defer ? &pending_close : nullptr, &opened)) return rc;
         s->logical[1] = promote(s->logical[1], s->logical[3]);
     }
     return NB_OK;

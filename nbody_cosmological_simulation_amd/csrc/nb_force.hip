@@ -204,7 +204,9 @@ force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
 
     const int tid = threadIdx.x;
     const int ibase = blockIdx.x * (NB_BLOCK * R);
-    bool degenerate = false;
+    bool degenerate = false, use_est = false;
+    float est_a = 0.0f, est_b = 0.0f;
+    int est_kmax = 0;
 
     if (HOOK == HOOK_GRID) {
         for (int k = tid; k < LP; k += NB_BLOCK) {
@@ -212,6 +214,10 @@ force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
             s_lut[k] = (k < tab->levels) ? tab->lut[k] : 0.0f;
         }
         degenerate = tab->degenerate != 0;
+        use_est = tab->use_est != 0;
+        est_a = tab->est_a;
+        est_b = tab->est_b;
+        est_kmax = tab->levels - 2;
     }
 
     float xi[R][D];
@@ -268,7 +274,11 @@ force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
                 float wq;   // (1 / q^1.5) * G   (simulation.py:97-101)
                 if (HOOK == HOOK_GRID) {
                     if (!degenerate) {
-                        wq = s_lut[grid_bin_lookup<LP>(s_thr, r2)];
+                        // floor estimate + one threshold compare (nb_device.h) when the tables allow it,
+                        // else the 8-step binary search: both give the exact bin
+                        const int kb = use_est ? grid_bin_floor_estimate(s_thr, r2, est_a, est_b, est_kmax)
+                                               : grid_bin_lookup<LP>(s_thr, r2);
+                        wq = s_lut[kb];
                     } else {
                         const float q = (r2 < 0.01f) ? 0.01f : r2;     // clamp keeps NaN
                         wq = inv_r3_f32(q) * G;
@@ -628,6 +638,7 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
         }
         tab->thr[k] = thr;
     }
+    __syncthreads();               // every thread has read tab->r2max_bits
     if (k == 0 && ps) {
         // the pruned max-r2 search is finished: reset its scratch for the next evaluation
         for (int c = 0; c < 3; ++c) { ps->box_min[c] = 0xffffffffu; ps->box_max[c] = 0u; }
@@ -655,6 +666,7 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
         tab->degenerate = (range < 1e-10f) ? 1 : 0;
         tab->levels = levels;
         tab->uniform_ok = (tab->use_est && r2max < 1e30f) ? 1 : 0;   // false for NaN / inf r2max too
+        tab->r2max_bits = 0u;      // consumed (every thread read it on entry): ready for the next atomicMax round
     }
 }
 

@@ -117,13 +117,18 @@ hipError_t nb_launch_d2bins(const float *pos, int n, int dim, float eps2, const 
 
 // reduce the S partial slabs in fixed order; optionally fuse the closing half kick
 hipError_t nb_launch_reduce(const double *partial, int nchunks, int64_t count, void *acc, int is_f64,
-                            void *vel, double half_dt, int do_kick, hipStream_t st);
+                            void *vel, double half_dt, int do_kick /* 1: closing kick, 2: + next opening kick + drift */,
+                            void *pos, double dt, hipStream_t st);
 hipError_t nb_launch_axpy(void *y, const void *x, double scalar, int64_t count, int is_f64, hipStream_t st);
 hipError_t nb_launch_kick_drift(void *pos, void *vel, const void *acc, double half_dt, double dt,
                                 int64_t count, int is_f64, hipStream_t st);
 hipError_t nb_launch_convert(const void *in, int in_dt, void *out, int out_dt, int64_t count, hipStream_t st);
 
 // linear force grid (quantization.py:74-88) applied in place inside the step, fp32, with bin output
+hipError_t nb_launch_force_quant_step(float *acc, int64_t count, int levels, double *mn_mx, double *partials,
+                                      int16_t *bins, float *vel, float *pos, double half_dt, double dt,
+                                      int kick /* 0 none, 1 closing kick, 2 + next opening kick + drift */,
+                                      hipStream_t st);
 hipError_t nb_launch_force_quant_bins(const float *in, float *out, int64_t count, int levels, const double *mn_mx,
                                       int16_t *bins, hipStream_t st);
 

@@ -26,7 +26,7 @@ __device__ __forceinline__ double axpy1(double a, double b, double s) { return _
 template <typename T>
 __global__ void __launch_bounds__(EW_BLOCK)
 reduce_kernel(const double *__restrict__ partial, int nchunks, int64_t count, T *__restrict__ acc,
-              T *__restrict__ vel, T half_dt, int do_kick)
+              T *__restrict__ vel, T half_dt, int do_kick, T *__restrict__ pos, T dt)
 {
     for (int64_t idx = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < count;
          idx += (int64_t)gridDim.x * EW_BLOCK) {
@@ -34,7 +34,16 @@ reduce_kernel(const double *__restrict__ partial, int nchunks, int64_t count, T 
         for (int c = 1; c < nchunks; ++c) s += partial[(size_t)c * count + idx];
         const T a = (T)s;
         acc[idx] = a;
-        if (do_kick) vel[idx] = axpy1(vel[idx], a, half_dt);
+        if (do_kick == 1) {
+            vel[idx] = axpy1(vel[idx], a, half_dt);
+        } else if (do_kick == 2) {
+            // closing kick of this step and the opening kick + drift of the next one (simulation.py:141,
+            // then :132,:135 of the following step()): the same operations the separate launches perform
+            T v = axpy1(vel[idx], a, half_dt);
+            v = axpy1(v, a, half_dt);
+            vel[idx] = v;
+            pos[idx] = axpy1(pos[idx], v, dt);
+        }
     }
 }
 
@@ -196,6 +205,50 @@ grid_quantize_kernel(const T *in, T *out /* may alias in */, int64_t count, int 
         if (!passthrough) v = lin_quant<T>(v, mn, range, lm1, &b);
         out[idx] = v;
         if (bins) bins[idx] = (int16_t)b;
+    }
+}
+
+// Force quantisation inside a step (simulation.py:115-116 -> quantization.py:74-88), second half: every block
+// folds the stage-1 min/max partials itself (min/max are exact, so every block gets the same bounds), then
+// quantises its elements; optionally the closing half kick (simulation.py:141) and the next step's opening kick +
+// drift (:132,:135) ride along -- the same operations the separate launches perform.
+__global__ void __launch_bounds__(256)
+force_quant_finish_kernel(float *__restrict__ acc, int64_t count, int levels, const double *__restrict__ partials,
+                          int nblocks, double *__restrict__ mn_mx, int16_t *__restrict__ bins, float *__restrict__ vel,
+                          float *__restrict__ pos, float half_dt, float dt, int kick)
+{
+    __shared__ double s_mn[4], s_mx[4];
+    __shared__ double s_out[2];
+    double dmn = __builtin_inf(), dmx = -__builtin_inf();
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        dmn = nan_min(dmn, partials[2 * i]);
+        dmx = nan_max(dmx, partials[2 * i + 1]);
+    }
+    minmax_fold<double>(dmn, dmx, s_mn, s_mx);
+    if (threadIdx.x == 0) {
+        s_out[0] = dmn;
+        s_out[1] = dmx;
+        if (blockIdx.x == 0) { mn_mx[0] = dmn; mn_mx[1] = dmx; }
+    }
+    __syncthreads();
+    const float mn = (float)s_out[0], mx = (float)s_out[1];
+    const float range = __fsub_rn(mx, mn);
+    const bool passthrough = range < 1e-10f;
+    const float lm1 = (float)(levels - 1);
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (int64_t)gridDim.x * 256) {
+        int b = -1;
+        float a = acc[idx];
+        if (!passthrough) a = lin_quant<float>(a, mn, range, lm1, &b);
+        acc[idx] = a;
+        if (bins) bins[idx] = (int16_t)b;
+        if (kick) {
+            float v = axpy1(vel[idx], a, half_dt);
+            if (kick == 2) {
+                v = axpy1(v, a, half_dt);
+                pos[idx] = axpy1(pos[idx], v, dt);
+            }
+            vel[idx] = v;
+        }
     }
 }
 
@@ -389,15 +442,15 @@ potential_kernel(const T *__restrict__ pos, const T *__restrict__ mass, ForceGeo
 // launchers
 // ---------------------------------------------------------------------------------------------
 hipError_t nb_launch_reduce(const double *partial, int nchunks, int64_t count, void *acc, int is_f64, void *vel,
-                            double half_dt, int do_kick, hipStream_t st)
+                            double half_dt, int do_kick, void *pos, double dt, hipStream_t st)
 {
     const int grid = ew_grid(count);
     if (is_f64)
         hipLaunchKernelGGL((reduce_kernel<double>), dim3(grid), dim3(EW_BLOCK), 0, st, partial, nchunks, count,
-                           (double *)acc, (double *)vel, half_dt, do_kick);
+                           (double *)acc, (double *)vel, half_dt, do_kick, (double *)pos, dt);
     else
         hipLaunchKernelGGL((reduce_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, st, partial, nchunks, count,
-                           (float *)acc, (float *)vel, (float)half_dt, do_kick);
+                           (float *)acc, (float *)vel, (float)half_dt, do_kick, (float *)pos, (float)dt);
     return hipGetLastError();
 }
 
@@ -471,6 +524,22 @@ hipError_t nb_launch_force_quant_bins(const float *in, float *out, int64_t count
     const int grid = ew_grid(count);
     hipLaunchKernelGGL((grid_quantize_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, st, in, out, count, levels,
                        mn_mx, bins);
+    return hipGetLastError();
+}
+
+// min/max of the summed forces + quantisation (+ kicks) of the step: two launches
+hipError_t nb_launch_force_quant_step(float *acc, int64_t count, int levels, double *mn_mx, double *partials,
+                                      int16_t *bins, float *vel, float *pos, double half_dt, double dt, int kick,
+                                      hipStream_t st)
+{
+    int blocks = (int)((count + 1023) / 1024);
+    blocks = blocks < 1 ? 1 : (blocks > MM_BLOCKS ? MM_BLOCKS : blocks);
+    hipLaunchKernelGGL((minmax_stage1_kernel<float, false>), dim3(blocks), dim3(256), 0, st, (const float *)acc, count,
+                       0.0f, partials);
+    int grid = (int)((count + 255) / 256);
+    grid = grid > 2048 ? 2048 : grid;
+    hipLaunchKernelGGL(force_quant_finish_kernel, dim3(grid), dim3(256), 0, st, acc, count, levels, partials, blocks,
+                       mn_mx, bins, vel, pos, (float)half_dt, (float)dt, kick);
     return hipGetLastError();
 }
 
