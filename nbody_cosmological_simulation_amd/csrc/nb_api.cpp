@@ -215,10 +215,12 @@ int build_sym_plan(nb_sim *s)
     // plan of their rank (tests: the partial sums of all ranks' plans must add up to the full result)
     if (!want || ((c.flags & NB_FLAG_NO_COMM) && want < 2)) return NB_OK;
     if (s->is_f64 && c.mode != NB_FLOAT64) return NB_OK;    // fp64 state under a cast mode: one-sided kernel
-    sp.r = (c.dim == 2) ? 4 : 2;       // measured on MI355X, N=65536: R=1 3.39 ms, R=2 1.87 ms, R=4 1.47 ms
+    // targets per lane.  Measured on MI355X, N=65536, D=2: R=1 3.39 ms, R=2 1.87 ms, R=4 1.47 ms.  D=3 also keeps
+    // four targets per lane and sweeps the source tile in two halves of two slots (sym_rj, nb_force_sym.hip)
+    sp.r = 4;
     if (const char *e = getenv("NB_SYM_R")) {
         const int r = atoi(e);
-        if ((r == 1 && s->is_f64) || r == 2 || (r == 4 && c.dim == 2)) sp.r = r;
+        if ((r == 1 && s->is_f64 && c.dim == 2) || r == 2 || r == 4) sp.r = r;
     }
     sp.tile_b = 64 * sp.r;
     const int Treal = (c.n + sp.tile_b - 1) / sp.tile_b;      // tiles that hold particles
@@ -226,6 +228,13 @@ int build_sym_plan(nb_sim *s)
     sp.tiles = SR * 4;                                         // padded tile count
     sp.np = sp.tiles * sp.tile_b;
     const int T = Treal, P = c.nranks;
+    // The choice between this plan and the one-sided source blocks must be the same on every rank (their
+    // partial sums are added): it may only depend on rank-independent quantities.  Fewer super-rows than
+    // ranks would leave a rank without work; the slab budget is checked for the worst case (every owned
+    // super-row cut into four pieces).
+    const size_t el = s->is_f64 ? sizeof(double) : sizeof(float);
+    if (SR < P) return NB_OK;
+    if ((size_t)c.dim * sp.np * el * (size_t)(4 * ((SR + P - 1) / P)) > (size_t)48 << 30) return NB_OK;
     std::vector<int> ord(SR, -1), slot0(sp.tiles, 0), nslots(sp.tiles, 0);
     long long owned_pairs = 0;
     int nrows = 0;
@@ -297,12 +306,10 @@ int build_sym_plan(nb_sim *s)
     std::stable_sort(work.begin(), work.end(), [](const SymWork &a, const SymWork &b) {
         return (long long)(a.jt_end - a.jt_begin) * a.s_count > (long long)(b.jt_end - b.jt_begin) * b.s_count;
     });
-    const size_t el = s->is_f64 ? sizeof(double) : sizeof(float);
     const size_t col_bytes = (size_t)c.dim * sp.np * el * (size_t)std::max(ncol, 1);
-    if (col_bytes > (size_t)48 << 30) return NB_OK;       // fall back to the one-sided kernel
     sp.nwork = (int)work.size();
     sp.nslots = slots;
-    if (sp.nwork == 0) return NB_OK;
+    if (sp.nwork == 0) return fail(NB_ERR_INVALID, "symmetric plan without work on rank %d", c.rank);
     HIPCHK(hipMalloc((void **)&sp.work, work.size() * sizeof(SymWork)));
     HIPCHK(hipMalloc((void **)&sp.row_slot0, sp.tiles * sizeof(int)));
     HIPCHK(hipMalloc((void **)&sp.row_nslots, sp.tiles * sizeof(int)));
@@ -484,7 +491,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
             return fail(NB_ERR_UNSUPPORTED, "mixed fp32 positions in fp64 storage under a cast mode");
         const int pair_dt = (qhook < 0 && s->logical[0] != NB_F64) ? s->logical[0] : -1;   // NB_F32 / F16 / BF16
         const int pa_f32 = (pair_dt == NB_F32);
-        const bool sym_default_shape = (c.dim == 2 && s->sym.r == 4) || (c.dim == 3 && s->sym.r == 2);
+        const bool sym_default_shape = s->sym.r == 4 || (c.dim == 3 && s->sym.r == 2);   // HOOK_F32PAIR instantiations
         used_sym = s->sym.enabled && qhook < 0 && (pair_dt < 0 || (pa_f32 && sym_default_shape));
         sym_uniform = s->mass_uniform;
         if (used_sym) {

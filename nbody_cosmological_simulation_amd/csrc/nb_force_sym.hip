@@ -77,6 +77,11 @@ __device__ __forceinline__ float inv_r3_sym(float q, float c15, float)
     return __builtin_fmaf(ve, c15, v);
 }
 
+// Source slots per sweep: the whole tile (R) in 2-D; in 3-D four targets and four sources per lane do not fit
+// 128 VGPRs, so the source tile is swept in two halves of two slots (8 pairs per lane per rotation step
+// instead of the 4 of an R = 2 tiling).
+constexpr int sym_rj(int d, int r) { return (d == 3 && r == 4) ? 2 : r; }
+
 struct GridArgs {
     const float *thr, *lut;
     const float4 *rec;      // rec[k] = {thr[k+1], lut[k], lut[k+1], -} for the one-access estimate path
@@ -85,15 +90,16 @@ struct GridArgs {
     bool degenerate;
 };
 
-// One tile-vs-tile sweep: `nsteps` rotation steps (64 = the whole tile pair), R*R pairs per lane per
-// step, J data rotating by one lane per step.
+// One sweep of a target tile (R particles per lane) against RJ source slots: `nsteps` rotation steps (64 = all
+// lanes), R*RJ pairs per lane per step, J data rotating by one lane per step.  RJ = R covers the whole
+// source tile; D = 3 sweeps it in two halves (RJ = 2) to stay inside 128 VGPRs with R = 4 targets.
 // DIAG:    J is the target tile itself -> one-sided (each ordered pair once, mirrors dropped).
 // UNIFORM: all masses equal -> the mass factor is applied once to the finished sums
 //          (reduce_sym_kernel), saving both mass multiplies and the rotation of the masses.
 // HOOK:    precision hook applied to the fp32 r2 (HOOK_NONE for fp64); EST: grid bins by estimate.
-template <typename T, int D, int R, bool DIAG, bool UNIFORM, int HOOK, int EST>
-__device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (&ai)[R][D], T (&xj)[R][D],
-                                      T (&gj)[R], T (&aj)[R][D], T eps2, int rot_addr, const GridArgs &ga,
+template <typename T, int D, int R, int RJ, bool DIAG, bool UNIFORM, int HOOK, int EST>
+__device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (&ai)[R][D], T (&xj)[RJ][D],
+                                      T (&gj)[RJ], T (&aj)[RJ][D], T eps2, int rot_addr, const GridArgs &ga,
                                       int nsteps)
 {
     T c15 = (T)1.5, c1875 = (T)1.875;
@@ -103,7 +109,7 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
         // source slot outermost: once all targets have met source rj its data and accumulator are
         // final for this step, so their rotation is issued at once and overlaps the remaining slots
 #pragma unroll
-        for (int rj = 0; rj < R; ++rj) {
+        for (int rj = 0; rj < RJ; ++rj) {
 #pragma unroll
             for (int ri = 0; ri < R; ++ri) {
                 T d[D];
@@ -189,16 +195,16 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2 rot1_f2(f2 v, int addr) { return f2{rot1<float>(v.x, addr), rot1<float>(v.y, addr)}; }
 
-template <int D, int R, bool DIAG, bool UNIFORM, int HOOK, int EST>
+template <int D, int R, int RJ, bool DIAG, bool UNIFORM, int HOOK, int EST>
 __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&gi)[R], f2 (&ai2)[R][D],
-                                         f2 (&xj2)[R / 2][D], f2 (&gj2)[R / 2], f2 (&aj2)[R / 2][D], float eps2,
+                                         f2 (&xj2)[RJ / 2][D], f2 (&gj2)[RJ / 2], f2 (&aj2)[RJ / 2][D], float eps2,
                                          int rot_addr, const GridArgs &ga, int nsteps)
 {
     const f2 c15 = {1.5f, 1.5f}, one = {1.0f, 1.0f};
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
 #pragma unroll
-        for (int h = 0; h < R / 2; ++h) {
+        for (int h = 0; h < RJ / 2; ++h) {
 #pragma unroll
             for (int ri = 0; ri < R; ++ri) {
                 f2 d[D];
@@ -268,9 +274,10 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                  T *__restrict__ colslab, int np, T eps2, const GridTables *__restrict__ tab, float gfac, int gate)
 {
     constexpr int B = 64 * R;
+    constexpr int RJ = sym_rj(D, R);            // source slots per sweep
     constexpr int W = NB_BLOCK / 64;
     constexpr bool F32 = std::is_same_v<T, float>;
-    __shared__ T s_aj[W][R][D][64];
+    __shared__ T s_aj[W][RJ][D][64];
     __shared__ float s_thr[HOOK == HOOK_GRID ? NB_MAX_LUT + 1 : 1];
     __shared__ float s_lut[HOOK == HOOK_GRID ? NB_MAX_LUT + 1 : 1];
     __shared__ float4 s_rec[HOOK == HOOK_GRID ? NB_MAX_LUT : 1];
@@ -323,22 +330,24 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
     }
 
     for (int J = wk.jt_begin; J < wk.jt_end; ++J) {     // all four waves take the same source tile
-        T aj[R][D];
+      for (int half = 0; half < R / RJ; ++half) {       // ... in R / RJ parts of RJ source slots each
+        const int hs = half * RJ;                       // first source slot of this part
+        T aj[RJ][D];
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+        for (int r = 0; r < RJ; ++r)
 #pragma unroll
             for (int k = 0; k < D; ++k) aj[r][k] = (T)0;
         if (J >= I) {                                   // wave-uniform; tiles below the diagonal belong to other rows
             const bool diag = (J == I);
-            if constexpr (F32 && (R % 2 == 0) && (HOOK != HOOK_GRID || UNIFORM)) {
+            if constexpr (F32 && (RJ % 2 == 0) && (HOOK != HOOK_GRID || UNIFORM)) {
                 // fp32 modes: source slots (2h, 2h+1) packed in float2 halves (sweep_pk).  The general-mass
                 // grid kernel keeps the scalar loop (the packed form spills there); the uniform-mass one
                 // always has a usable estimate (GridTables::uniform_ok gates it).
-                f2 xj2[R / 2][D], gj2[R / 2], aj2[R / 2][D], ai2[R][D];
+                f2 xj2[RJ / 2][D], gj2[RJ / 2], aj2[RJ / 2][D], ai2[R][D];
 #pragma unroll
-                for (int h = 0; h < R / 2; ++h) {
+                for (int h = 0; h < RJ / 2; ++h) {
                     // a split sweep starts s_begin rotation steps in: lane l meets particle (l + s_begin) first
-                    const int p0 = J * B + (2 * h) * 64 + ((lane + wk.s_begin) & 63);
+                    const int p0 = J * B + (hs + 2 * h) * 64 + ((lane + wk.s_begin) & 63);
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
                         xj2[h][k] = f2{packed[(size_t)k * np + p0], packed[(size_t)k * np + p0 + 64]};
@@ -351,17 +360,17 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
 #pragma unroll
                     for (int k = 0; k < D; ++k) ai2[r][k] = f2{0.0f, 0.0f};
                 if (HOOK == HOOK_GRID && few_levels) {
-                    if (diag) sweep_pk<D, R, true, UNIFORM, HOOK, 1>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
-                    else sweep_pk<D, R, false, UNIFORM, HOOK, 1>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    if (diag) sweep_pk<D, R, RJ, true, UNIFORM, HOOK, 1>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    else sweep_pk<D, R, RJ, false, UNIFORM, HOOK, 1>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
                 } else if (HOOK == HOOK_GRID) {
-                    if (diag) sweep_pk<D, R, true, UNIFORM, HOOK, 2>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
-                    else sweep_pk<D, R, false, UNIFORM, HOOK, 2>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    if (diag) sweep_pk<D, R, RJ, true, UNIFORM, HOOK, 2>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    else sweep_pk<D, R, RJ, false, UNIFORM, HOOK, 2>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
                 } else {
-                    if (diag) sweep_pk<D, R, true, UNIFORM, HOOK, 0>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
-                    else sweep_pk<D, R, false, UNIFORM, HOOK, 0>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    if (diag) sweep_pk<D, R, RJ, true, UNIFORM, HOOK, 0>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    else sweep_pk<D, R, RJ, false, UNIFORM, HOOK, 0>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
                 }
 #pragma unroll
-                for (int h = 0; h < R / 2; ++h)
+                for (int h = 0; h < RJ / 2; ++h)
 #pragma unroll
                     for (int k = 0; k < D; ++k) { aj[2 * h][k] = aj2[h][k].x; aj[2 * h + 1][k] = aj2[h][k].y; }
 #pragma unroll
@@ -369,26 +378,27 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
 #pragma unroll
                     for (int k = 0; k < D; ++k) ai_sum[r][k] += (double)(ai2[r][k].x + ai2[r][k].y);
             } else {
-                T xj[R][D], gj[R], ai[R][D];
+                T xj[RJ][D], gj[RJ], ai[R][D];
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int p = J * B + r * 64 + ((lane + wk.s_begin) & 63);
+                for (int r = 0; r < RJ; ++r) {
+                    const int p = J * B + (hs + r) * 64 + ((lane + wk.s_begin) & 63);
 #pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        xj[r][k] = packed[(size_t)k * np + p];
-                        ai[r][k] = F32 ? (T)0 : (T)ai_sum[r][k];
-                    }
+                    for (int k = 0; k < D; ++k) xj[r][k] = packed[(size_t)k * np + p];
                     gj[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
                 }
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int k = 0; k < D; ++k) ai[r][k] = F32 ? (T)0 : (T)ai_sum[r][k];
                 if (HOOK == HOOK_GRID && use_est && few_levels) {
-                    if (diag) sweep<T, D, R, true, UNIFORM, HOOK, 1>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
-                    else sweep<T, D, R, false, UNIFORM, HOOK, 1>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                    if (diag) sweep<T, D, R, RJ, true, UNIFORM, HOOK, 1>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                    else sweep<T, D, R, RJ, false, UNIFORM, HOOK, 1>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
                 } else if (HOOK == HOOK_GRID && use_est) {
-                    if (diag) sweep<T, D, R, true, UNIFORM, HOOK, 2>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
-                    else sweep<T, D, R, false, UNIFORM, HOOK, 2>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                    if (diag) sweep<T, D, R, RJ, true, UNIFORM, HOOK, 2>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                    else sweep<T, D, R, RJ, false, UNIFORM, HOOK, 2>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
                 } else {
-                    if (diag) sweep<T, D, R, true, UNIFORM, HOOK, 0>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
-                    else sweep<T, D, R, false, UNIFORM, HOOK, 0>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                    if (diag) sweep<T, D, R, RJ, true, UNIFORM, HOOK, 0>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
+                    else sweep<T, D, R, RJ, false, UNIFORM, HOOK, 0>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r)
@@ -396,27 +406,28 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                     for (int k = 0; k < D; ++k) ai_sum[r][k] = F32 ? ai_sum[r][k] + (double)ai[r][k] : (double)ai[r][k];
             }
         }
-        // column contributions of the super-row to tile J: the diagonal sweep leaves aj untouched (0),
-        // skipped waves hold 0; add the four waves in a fixed order and write ONE slab entry.
+        // column contributions of the super-row to these source slots of tile J: the diagonal sweep leaves aj
+        // untouched (0), skipped waves hold 0; add the four waves in a fixed order and write ONE slab entry.
         // After s_count rotations lane l holds the accumulators of particle (l + s_begin + s_count).
         const int home = (lane + wk.s_begin + wk.s_count) & 63;
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+        for (int r = 0; r < RJ; ++r)
 #pragma unroll
             for (int k = 0; k < D; ++k) s_aj[wave][r][k][home] = aj[r][k];
         __syncthreads();
         if (J > wk.tile_i) {                            // block-uniform: at least the first row lies below J
-            for (int idx = threadIdx.x; idx < R * D * 64; idx += NB_BLOCK) {
+            for (int idx = threadIdx.x; idx < RJ * D * 64; idx += NB_BLOCK) {
                 const int l = idx & 63, rk = idx >> 6;
                 const int r = rk / D, k = rk % D;
                 T v = s_aj[0][r][k][l];
 #pragma unroll
                 for (int w = 1; w < W; ++w) v += s_aj[w][r][k][l];
                 if (UNIFORM && HOOK == HOOK_GRID) v *= (T)gfac;      // gfac = the common mass here
-                colslab[((size_t)wk.col_ord * D + k) * np + (size_t)J * B + r * 64 + l] = v;
+                colslab[((size_t)wk.col_ord * D + k) * np + (size_t)J * B + (hs + r) * 64 + l] = v;
             }
         }
         __syncthreads();
+      }
     }
 
     // row sums: one compact slot per (row, chunk)
@@ -672,6 +683,7 @@ hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, in
         const float e32 = (float)eps2;
         if (dim == 2 && r == 4) return launch_sym_u<double, 2, 4, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st, ev);
         if (dim == 3 && r == 2) return launch_sym_u<double, 3, 2, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st, ev);
+        if (dim == 3 && r == 4) return launch_sym_u<double, 3, 4, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st, ev);
         return hipErrorInvalidValue;
     }
     if (dim == 2 && r == 1) return launch_sym_u<double, 2, 1, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st, ev);
@@ -679,6 +691,7 @@ hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, in
     if (dim == 2 && r == 4) return launch_sym_u<double, 2, 4, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st, ev);
     if (dim == 3 && r == 1) return launch_sym_u<double, 3, 1, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st, ev);
     if (dim == 3 && r == 2) return launch_sym_u<double, 3, 2, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st, ev);
+    if (dim == 3 && r == 4) return launch_sym_u<double, 3, 4, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, 1.0f, st, ev);
     return hipErrorInvalidValue;
 }
 
@@ -697,6 +710,7 @@ hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int
     if (dim == 2 && r == 2) { NB_SYM32(2, 2) }
     if (dim == 2 && r == 4) { NB_SYM32(2, 4) }
     if (dim == 3 && r == 2) { NB_SYM32(3, 2) }
+    if (dim == 3 && r == 4) { NB_SYM32(3, 4) }
 #undef NB_SYM32
     return hipErrorInvalidValue;
 }
@@ -712,11 +726,13 @@ hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int 
         if (dim == 2 && r == 4) { if (f32_terms) NB_PES(double, 2, 4, true); else NB_PES(double, 2, 4, false); }
         else if (dim == 2 && r == 2) { if (f32_terms) NB_PES(double, 2, 2, true); else NB_PES(double, 2, 2, false); }
         else if (dim == 3 && r == 2) { if (f32_terms) NB_PES(double, 3, 2, true); else NB_PES(double, 3, 2, false); }
+        else if (dim == 3 && r == 4) { if (f32_terms) NB_PES(double, 3, 4, true); else NB_PES(double, 3, 4, false); }
         else return hipErrorInvalidValue;
     } else {
         if (dim == 2 && r == 4) NB_PES(float, 2, 4, true);
         else if (dim == 2 && r == 2) NB_PES(float, 2, 2, true);
         else if (dim == 3 && r == 2) NB_PES(float, 3, 2, true);
+        else if (dim == 3 && r == 4) NB_PES(float, 3, 4, true);
         else return hipErrorInvalidValue;
     }
 #undef NB_PES

@@ -930,9 +930,12 @@ def test_symmetric_plan_of_every_rank_adds_up(nb, monkeypatch, world):
     cases.append(("f32 D2", p2, v2, m2 * torch.from_numpy(rng.uniform(0.5, 1.5, 9000).astype(np.float32)),
                   nb.PrecisionMode.FLOAT32, 2e-6))
     cases.append(("custom D2", p2, v2, m2, nb.PrecisionMode.CUSTOM, 2e-6))
-    p3 = torch.from_numpy((rng.standard_normal((5000, 3)) * 4).astype(np.float32))
-    cases.append(("f64 D3", p3.double(), torch.zeros(5000, 3, dtype=torch.float64), torch.ones(5000, dtype=torch.float64),
+    # 9000 particles = 9 super-rows of 1024: at least one per rank (with fewer super-rows than ranks every
+    # rank falls back to the one-sided source blocks -- the choice is rank-independent by construction)
+    p3 = torch.from_numpy((rng.standard_normal((9000, 3)) * 4).astype(np.float32))
+    cases.append(("f64 D3", p3.double(), torch.zeros(9000, 3, dtype=torch.float64), torch.ones(9000, dtype=torch.float64),
                   nb.PrecisionMode.FLOAT64, 1e-13))
+    cases.append(("f32 D3", p3, torch.zeros(9000, 3), torch.ones(9000), nb.PrecisionMode.FLOAT32, 2e-6))
     if world == 8:      # the driver's scaling run: BASELINE config 2 on 8 ranks (tail-smoothed plans)
         pb, vb, mb = galaxy.create_disk_galaxy(65536, seed=42, device="cpu")
         cases.append(("f64 N=65536", pb.double(), vb.double(), mb.double(), nb.PrecisionMode.FLOAT64, 1e-13))
