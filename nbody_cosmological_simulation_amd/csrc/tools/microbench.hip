@@ -19,20 +19,22 @@ constexpr int UNROLL = 8;
 
 // Each op kernel keeps UNROLL independent chains per lane so issue rate, not latency, is measured.
 enum { OP_FMA64, OP_MUL64, OP_ADD64, OP_RSQ64, OP_RCP64, OP_SQRT64, OP_CVT64_32, OP_CVT32_64, OP_FMA32, OP_RSQ32,
-       OP_MFMA64_4, OP_MFMA64_4_FMA6, OP_FMA64_X6, OP_MIX_PAIR, OP_NOPS };
+       OP_MFMA64_4, OP_MFMA64_4_FMA6, OP_FMA64_X6, OP_PKFMA32, OP_PKFMA32_RSQ, OP_MIX_PAIR, OP_NOPS };
 const char *OP_NAMES[] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rsq_f64", "v_rcp_f64", "v_sqrt_f64",
                           "v_cvt_f32_f64", "v_cvt_f64_f32", "v_fma_f32", "v_rsq_f32",
-                          "mfma_f64_4x4x4", "mfma4x4x4+6fma", "6 x v_fma_f64", "pair_body_f64"};
+                          "mfma_f64_4x4x4", "mfma4x4x4+6fma", "6 x v_fma_f64", "v_pk_fma_f32", "pk_fma+2rsq_f32",
+                          "pair_body_f64"};
 
 template <int OP>
 __global__ void __launch_bounds__(256) op_kernel(double *out, double seed)
 {
     double a[UNROLL], g[UNROLL][6];
-    float f[UNROLL];
+    float f[UNROLL], h[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
         a[u] = seed + threadIdx.x * 1e-3 + u;
         f[u] = (float)a[u];
+        h[u] = f[u] + 0.5f;
 #pragma unroll
         for (int k = 0; k < 6; ++k) g[u][k] = a[u] + k;
     }
@@ -50,6 +52,13 @@ __global__ void __launch_bounds__(256) op_kernel(double *out, double seed)
             if (OP == OP_CVT32_64) { a[u] = (double)f[u]; asm volatile("" : "+v"(a[u])); }
             if (OP == OP_FMA32) f[u] = __builtin_fmaf(f[u], 1.0000001f, 1e-9f);
             if (OP == OP_RSQ32) f[u] = __builtin_amdgcn_rsqf(f[u]);
+            if (OP == OP_PKFMA32 || OP == OP_PKFMA32_RSQ) {
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                f2v t = {f[u], h[u]};
+                t = __builtin_elementwise_fma(t, f2v{1.0000001f, 0.9999999f}, f2v{1e-9f, 2e-9f});
+                if (OP == OP_PKFMA32_RSQ) { t.x = __builtin_amdgcn_rsqf(t.x); t.y = __builtin_amdgcn_rsqf(t.y); }
+                f[u] = t.x; h[u] = t.y;
+            }
             // matrix pipe: does v_mfma_f64_4x4x4_4b overlap with VALU FMAs of the same and of other waves?
             if (OP == OP_MFMA64_4 || OP == OP_MFMA64_4_FMA6) a[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(b, c, a[u], 0, 0, 0);
             if (OP == OP_MFMA64_4_FMA6 || OP == OP_FMA64_X6) {
@@ -61,7 +70,7 @@ __global__ void __launch_bounds__(256) op_kernel(double *out, double seed)
     double s = 0;
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-        s += a[u] + f[u];
+        s += a[u] + f[u] + h[u];
         if (OP == OP_MFMA64_4_FMA6 || OP == OP_FMA64_X6)
 #pragma unroll
             for (int k = 0; k < 6; ++k) s += g[u][k];
@@ -155,7 +164,7 @@ int main()
 #define CASE(O) case O: hipLaunchKernelGGL(op_kernel<O>, dim3(grid), dim3(256), 0, 0, out, 1.5); break;
                     CASE(OP_FMA64) CASE(OP_MUL64) CASE(OP_ADD64) CASE(OP_RSQ64) CASE(OP_RCP64) CASE(OP_SQRT64)
                     CASE(OP_CVT64_32) CASE(OP_CVT32_64) CASE(OP_FMA32) CASE(OP_RSQ32)
-                    CASE(OP_MFMA64_4) CASE(OP_MFMA64_4_FMA6) CASE(OP_FMA64_X6)
+                    CASE(OP_MFMA64_4) CASE(OP_MFMA64_4_FMA6) CASE(OP_FMA64_X6) CASE(OP_PKFMA32) CASE(OP_PKFMA32_RSQ)
 #undef CASE
                 case OP_MIX_PAIR: hipLaunchKernelGGL(pair_kernel, dim3(grid), dim3(256), 0, 0, out, 1.5); break;
                 }
