@@ -582,9 +582,13 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         // uniform-mass kernels leave out the mass factor: G*m in T arithmetic (fp32: (float)G * m)
         double scale = 1.0;
         if (sym_uniform) scale = s->is_f64 ? c.G * s->mass_value : (double)((float)c.G * (float)s->mass_value);
+        // inside nb_step the reduction also opens the next step and repacks its positions (packed_ready says
+        // the fused pack flow is in use: uniform dtypes, no grid hook)
+        const bool open = fuse_kick && want_open && packed_ready;
         HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.col_upto,
-                                    sp.tile_b, c.n, sp.np, c.dim, s->is_f64, scale, s->acc, s->vel, half_dt, fuse_kick,
-                                    s->stream));
+                                    sp.tile_b, c.n, sp.np, c.dim, s->is_f64, scale, s->acc, s->vel, half_dt,
+                                    open ? 2 : (fuse_kick ? 1 : 0), s->pos, sp.packed, c.dt, s->stream));
+        opened = open;
     } else {
         // one-sided path inside nb_step: the reduction can also open the next step (one launch fewer per step,
         // which is what small systems are bound by)
@@ -819,7 +823,8 @@ int nb_step(nb_sim *s, int32_t nsteps)
         // a closing kick that cannot ride in the reduction (RCCL all-reduce / force quantisation in
         // between) is folded into the next step's opening launch when there is one
         const bool may_defer = (t + 1 < nsteps) && fuse_pack;
-        opened = (t + 1 < nsteps) && uniform_dt && (!s->sym.enabled || force_quant_mode(s->cfg));   // request; force_eval answers
+        opened = (t + 1 < nsteps) && uniform_dt &&
+                 (!s->sym.enabled || force_quant_mode(s->cfg) || fuse_pack);   // request; force_eval answers
         if (int rc = force_eval(s, true, fuse_pack, may_defer ? &pending_close : nullptr, &opened)) return rc;
         s->logical[1] = promote(s->logical[1], s->logical[3]);
     }

@@ -494,7 +494,8 @@ __global__ void __launch_bounds__(64 * NB_RED_WAVES)
 reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ colslab,
                   const int *__restrict__ row_slot0, const int *__restrict__ row_nslots,
                   const int *__restrict__ col_upto, int tile_b, int n, int np,
-                  double scale, T *__restrict__ acc, T *__restrict__ vel, T half_dt, int do_kick)
+                  double scale, T *__restrict__ acc, T *__restrict__ vel, T half_dt, int do_kick,
+                  T *__restrict__ pos, T *__restrict__ packed, T dt)
 {
     __shared__ double s_part[NB_RED_WAVES][D][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -528,7 +529,18 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
             const size_t idx = (size_t)p * D + k;
             const T a = (T)(t * scale);            // scale = mass factor of the uniform kernel, else 1
             acc[idx] = a;
-            if (do_kick) vel[idx] = axpy_rn<T>(vel[idx], a, half_dt);
+            if (do_kick == 1) {
+                vel[idx] = axpy_rn<T>(vel[idx], a, half_dt);
+            } else if (do_kick == 2) {
+                // closing kick, then the next step's opening kick + drift and its repack (what pack_kernel<KICK=1>
+                // would do in a launch of its own; mass factors and padding in `packed` do not change)
+                T v = axpy_rn<T>(vel[idx], a, half_dt);
+                v = axpy_rn<T>(v, a, half_dt);
+                const T x = axpy_rn<T>(pos[idx], v, dt);
+                vel[idx] = v;
+                pos[idx] = x;
+                packed[(size_t)k * np + p] = x;
+            }
         }
     }
 }
@@ -742,12 +754,13 @@ hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int 
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
                                 const int *row_nslots, const int *col_upto, int tile_b, int n,
                                 int np, int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
-                                int do_kick, hipStream_t st)
+                                int do_kick, void *pos, void *packed, double dt, hipStream_t st)
 {
     const int grid = (n + 63) / 64;
 #define NB_RED(TT, DD) \
     hipLaunchKernelGGL((reduce_sym_kernel<TT, DD>), dim3(grid), dim3(64 * NB_RED_WAVES), 0, st, rowslab, (const TT *)colslab, \
-                       row_slot0, row_nslots, col_upto, tile_b, n, np, scale, (TT *)acc, (TT *)vel, (TT)half_dt, do_kick)
+                       row_slot0, row_nslots, col_upto, tile_b, n, np, scale, (TT *)acc, (TT *)vel, (TT)half_dt, do_kick, \
+                       (TT *)pos, (TT *)packed, (TT)dt)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64) { if (dim == 2) NB_RED(double, 2); else NB_RED(double, 3); }
     else        { if (dim == 2) NB_RED(float, 2); else NB_RED(float, 3); }

@@ -90,7 +90,8 @@ hipError_t nb_launch_final_sum(const double *part, int count, double *out, hipSt
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
                                 const int *row_nslots, const int *col_upto, int tile_b, int n,
                                 int np, int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
-                                int do_kick, hipStream_t st);
+                                int do_kick /* 1: closing kick, 2: + next opening kick + drift + repack */,
+                                void *pos, void *packed, double dt, hipStream_t st);
 
 // ---- kernel launchers (implemented in the .hip files) --------------------------------------
 // T = storage/accumulation type of the state (float or double); pa_f32 != 0 selects fp32
