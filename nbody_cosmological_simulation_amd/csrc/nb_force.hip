@@ -735,9 +735,18 @@ hipError_t nb_launch_force_f64(const double *pos, const double *mass, double *pa
 hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *partial, const ForceGeom &g,
                                int dim, int hook, int pa, float G, float eps2, const GridTables *tab, hipStream_t st)
 {
-    const dim3 grid((g.n + NB_BLOCK * R_F32 - 1) / (NB_BLOCK * R_F32), g.nchunks);
-#define NB_F32K(DD, HH, LL, PP) \
-    hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HH, LL, PP>), grid, dim3(NB_BLOCK), 0, st, pos, mass, partial, g, G, eps2, tab)
+    // small systems are parallelism-bound: one target per thread doubles the workgroups (like the fp64 kernel)
+    const int r = g.n <= 8192 ? 1 : R_F32;
+    const dim3 grid((g.n + NB_BLOCK * r - 1) / (NB_BLOCK * r), g.nchunks);
+#define NB_F32K(DD, HH, LL, PP)                                                                                          \
+    do {                                                                                                                 \
+        if (r == 1)                                                                                                      \
+            hipLaunchKernelGGL((force_f32_kernel<DD, 1, HH, LL, PP>), grid, dim3(NB_BLOCK), 0, st, pos, mass, partial, g, \
+                               G, eps2, tab);                                                                            \
+        else                                                                                                             \
+            hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HH, LL, PP>), grid, dim3(NB_BLOCK), 0, st, pos, mass, partial, \
+                               g, G, eps2, tab);                                                                         \
+    } while (0)
     return dispatch_dim(dim, [&](auto D) {
         constexpr int DD = decltype(D)::value;
         if (pa != NB_F32) {
@@ -769,11 +778,14 @@ hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *part
 hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float eps2, GridTables *tab,
                            hipStream_t st)
 {
-    constexpr int R = 4;
-    const dim3 grid((g.n + NB_BLOCK * R - 1) / (NB_BLOCK * R), g.nchunks);
+    // small systems (the only ones that take this path by default): one target per thread, four times the
+    // workgroups
+    const int r = g.n <= 8192 ? 1 : 4;
+    const dim3 grid((g.n + NB_BLOCK * r - 1) / (NB_BLOCK * r), g.nchunks);
     return dispatch_dim(dim, [&](auto D) {
         constexpr int DD = decltype(D)::value;
-        hipLaunchKernelGGL((r2max_kernel<DD, R>), grid, dim3(NB_BLOCK), 0, st, pos, g, eps2, tab);
+        if (r == 1) hipLaunchKernelGGL((r2max_kernel<DD, 1>), grid, dim3(NB_BLOCK), 0, st, pos, g, eps2, tab);
+        else hipLaunchKernelGGL((r2max_kernel<DD, 4>), grid, dim3(NB_BLOCK), 0, st, pos, g, eps2, tab);
         return hipGetLastError();
     });
 }
