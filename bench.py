@@ -144,7 +144,7 @@ def main():
         sim.synchronize()
 
     sim.run(args.warmup)
-    # the chip needs ~30 launches (~40 ms) to settle at its sustained clock (profiles/r01_v7_clock_ramp.txt):
+    # the chip needs ~30 launches (~40 ms) to settle at its sustained clock (profiles/r01_v8_clock_ramp.txt):
     # short warm-ups are topped up with force evaluations that leave the state untouched (untimed)
     spinup = max(0, SPINUP_EVALS - args.warmup) if n >= 16384 else 0
     sim.spin_up(spinup)

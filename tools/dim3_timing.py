@@ -10,7 +10,7 @@ vel = torch.randn(n, 3) * 0.05
 mass = torch.ones(n)
 for mode in (nb.PrecisionMode.FLOAT64, nb.PrecisionMode.FLOAT32, nb.PrecisionMode.INT8_SIM):
     sim = nb.GalaxySimulation(pos.cuda(), vel.cuda(), mass.cuda(), precision_mode=mode, profile=True)
-    sim.run(40); sim.synchronize(); sim.kernel_time()      # 40 steps: past the clock ramp (profiles/r01_v7_clock_ramp.txt)
+    sim.run(40); sim.synchronize(); sim.kernel_time()      # 40 steps: past the clock ramp (profiles/r01_v8_clock_ramp.txt)
     t = time.perf_counter(); sim.run(100); sim.synchronize(); dt = time.perf_counter() - t
     ms, k = sim.kernel_time()
     flops = 19.0 * n * n        # 5D+4 per ordered pair
