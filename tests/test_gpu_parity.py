@@ -834,7 +834,7 @@ def test_randomised_configurations_vs_oracle(nb, monkeypatch):
         mass = (np.full(n, 1.3) if uniform else 0.2 + 2 * rng.random(n)).astype(dtype)
         monkeypatch.setenv("NB_SYM", str(sym))
         if sym:
-            monkeypatch.setenv("NB_SYM_R", str(2 if d == 3 else int(rng.choice([2, 4]))))
+            monkeypatch.setenv("NB_SYM_R", str(int(rng.choice([2, 4]))))      # D = 3, R = 4: two-half source sweeps
         sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode(mode), G=G,
                                   softening=eps, dt=dt)
         ref = O.OracleSim(pos, vel, mass, mode, G=G, softening=eps, dt=dt)
