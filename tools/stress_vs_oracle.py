@@ -1,0 +1,54 @@
+"""One-off randomised stress campaign against the oracle (larger than the seeded sweep in tests/): N, D, mode,
+softening, G, dt, masses, kernel family, tile shape, steps and step batching are all drawn at random.
+
+    python tools/stress_vs_oracle.py SEED CASES
+"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import nbody_cosmological_simulation_amd as nb
+from oracle import oracle as O
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-300)
+T = torch.from_numpy
+GRID = ("int8_sim", "int4_sim", "custom")
+seed = int(sys.argv[1]); ncases = int(sys.argv[2])
+rng = np.random.default_rng(seed)
+modes = ["float64", "float64", "float32", "bfloat16", "float16", "int8_sim", "int4_sim", "custom"]
+bad = 0
+for case in range(ncases):
+    n = int(rng.integers(2, 1600)); d = int(rng.choice([2, 3])); mode = modes[case % len(modes)]
+    eps = float(rng.choice([0.01, 0.05, 0.1, 0.3])); G = float(rng.choice([1e-3, 5e-3, 1e-2])); dt = float(rng.choice([0.005, 0.01, 0.02]))
+    steps = int(rng.integers(1, 5)); sym = int(rng.integers(0, 2)); uniform = bool(rng.integers(0, 2))
+    f64_in = mode == "float64" and bool(rng.integers(0, 2)); dtype = np.float64 if f64_in else np.float32
+    pos = (rng.standard_normal((n, d)) * rng.choice([1.0, 5.0, 20.0])).astype(dtype)
+    vel = (rng.standard_normal((n, d)) * 0.05).astype(dtype)
+    mass = (np.full(n, 1.3) if uniform else 0.2 + 2 * rng.random(n)).astype(dtype)
+    os.environ["NB_SYM"] = str(sym)
+    if sym: os.environ["NB_SYM_R"] = str(int(rng.choice([2, 4])))
+    else: os.environ.pop("NB_SYM_R", None)
+    tag = f"case {case}: n={n} d={d} {mode} eps={eps} sym={sym} R={os.environ.get('NB_SYM_R')} uniform={uniform} f64_in={f64_in} steps={steps}"
+    try:
+        sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode(mode), G=G, softening=eps, dt=dt)
+        ref = O.OracleSim(pos, vel, mass, mode, G=G, softening=eps, dt=dt)
+        quant = mode in ("int8_sim", "int4_sim")
+        if mode in GRID:
+            dbg = O.accelerations(pos, mass, mode, G=G, softening=eps, debug=True)[1]
+            got = sim.quant_debug(bins=True)
+            assert np.array_equal(got["d2bins"], dbg["d2bins"]), "d2bins"
+            if quant and int((got["fbins"] != dbg["fbins"]).sum()) > 0:
+                continue
+        tol = 1e-12 if mode == "float64" else 3e-6
+        e = relerr(sim.accelerations.numpy(), ref.accelerations); assert e < tol, ("acc", e)
+        # split the steps over two run() calls half of the time: fused and unfused step boundaries
+        if steps > 1 and rng.integers(0, 2): sim.run(1); sim.run(steps - 1)
+        else: sim.run(steps)
+        ref.run(steps)
+        if not quant:
+            e2 = relerr(sim.positions.numpy(), ref.positions); assert e2 < (1e-12 if mode == "float64" else 1e-5), ("pos", e2)
+            e3 = relerr(sim.velocities.numpy(), ref.velocities); assert e3 < (1e-11 if mode == "float64" else 1e-4), ("vel", e3)
+            ee, er = sim.get_total_energy(), ref.get_total_energy()
+            assert abs(ee - er) <= (1e-11 if mode == "float64" else 2e-5) * abs(er) + 1e-12, ("E", ee, er)
+    except AssertionError as ex:
+        bad += 1; print("FAIL", tag, ex, flush=True)
+print("done", ncases, "cases, failures:", bad)
