@@ -563,12 +563,13 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
             HIPCHK(nb_launch_force_sym_f32((const float *)sp.packed, sp.work, sp.nwork, sp.rowslab,
                                            (float *)sp.colslab, sp.np, c.dim, sp.r,
                                            hook == HOOK_GRID ? s->mass_uniform : sym_uniform, hook, eps2, s->tab,
-                                           (float)c.G, (float)s->mass_value, s->stream, prof_events(s, slot)));
+                                           (float)c.G, (float)s->mass_value, hook == HOOK_GRID ? mode_levels(c) : 0,
+                                           s->stream, prof_events(s, slot)));
             s->last_kernel = "force_sym_kernel<float";
         } else {
             if (int rc = prof_begin(s, &slot)) return rc;
             HIPCHK(nb_launch_force_f32((const float *)s->pos, (const float *)s->mass, s->partial, s->geom, c.dim, hook,
-                                       pa, (float)c.G, eps2, s->tab, s->stream));
+                                       pa, (float)c.G, eps2, s->tab, hook == HOOK_GRID ? mode_levels(c) : 0, s->stream));
             s->last_kernel = "force_f32_kernel";
             if (int rc = prof_end(s, slot)) return rc;
         }

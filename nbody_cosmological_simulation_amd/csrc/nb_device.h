@@ -18,12 +18,11 @@ __device__ __forceinline__ float r2_f32_exact(const float *d, float eps2)
 }
 
 // bin index = number of thresholds <= r2 (branch-free binary search over the LDS table)
-template <int LP>
-__device__ __forceinline__ int grid_bin_lookup(const float *thr, float r2)
+// lp: table size (power of two, entries beyond the levels hold +inf)
+__device__ __forceinline__ int grid_bin_lookup(const float *thr, float r2, int lp)
 {
     int k = 0;
-#pragma unroll
-    for (int step = LP / 2; step >= 1; step >>= 1)
+    for (int step = lp >> 1; step >= 1; step >>= 1)
         k += (thr[k + step] <= r2) ? step : 0;
     return k;
 }

@@ -192,15 +192,15 @@ force_f64_kernel(const double *__restrict__ pos, const double *__restrict__ mass
 // ------------------------------------------------------------------------------------------
 // fp32 state (FLOAT32 / BFLOAT16 / FLOAT16 / INT8 / INT4 / CUSTOM modes)
 // ------------------------------------------------------------------------------------------
-template <int D, int R, int HOOK, int LP, int PA = NB_F32>
+template <int D, int R, int HOOK, int PA = NB_F32>
 __global__ void __launch_bounds__(NB_BLOCK)
 force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
                  double *__restrict__ partial, ForceGeom g, float G, float eps2,
-                 const GridTables *__restrict__ tab)
+                 const GridTables *__restrict__ tab, int lp)
 {
     __shared__ float sj[D + 1][NB_TJ];
-    __shared__ float s_thr[HOOK == HOOK_GRID ? LP : 1];
-    __shared__ float s_lut[HOOK == HOOK_GRID ? LP : 1];
+    extern __shared__ float s_tables[];        // grid hook: thr[lp + 1], lut[lp + 1] (nb_lut_lds_bytes)
+    float *s_thr = s_tables, *s_lut = s_tables + lp + 1;
 
     const int tid = threadIdx.x;
     const int ibase = blockIdx.x * (NB_BLOCK * R);
@@ -209,7 +209,7 @@ force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
     int est_kmax = 0;
 
     if (HOOK == HOOK_GRID) {
-        for (int k = tid; k < LP; k += NB_BLOCK) {
+        for (int k = tid; k < lp; k += NB_BLOCK) {
             s_thr[k] = (k < tab->levels) ? tab->thr[k] : __builtin_inff();
             s_lut[k] = (k < tab->levels) ? tab->lut[k] : 0.0f;
         }
@@ -277,7 +277,7 @@ force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
                         // floor estimate + one threshold compare (nb_device.h) when the tables allow it,
                         // else the 8-step binary search: both give the exact bin
                         const int kb = use_est ? grid_bin_floor_estimate(s_thr, r2, est_a, est_b, est_kmax)
-                                               : grid_bin_lookup<LP>(s_thr, r2);
+                                               : grid_bin_lookup(s_thr, r2, lp);
                         wq = s_lut[kb];
                     } else {
                         const float q = (r2 < 0.01f) ? 0.01f : r2;     // clamp keeps NaN
@@ -596,11 +596,14 @@ __device__ __forceinline__ float grid_bin_exact(float t, float min_val, float lm
     return rintf(nrm);   // half-to-even like torch.round
 }
 
-__global__ void __launch_bounds__(NB_MAX_LUT)
+// One thread per level, NB_LUT_MIN threads per block; the block that arrives last (all others have read
+// tab->r2max_bits and written their entries) writes the scalars and resets the scratch for the next evaluation.
+__global__ void __launch_bounds__(NB_LUT_MIN)
 grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2, float min_val,
                    PruneState *__restrict__ ps)
 {
-    const int k = threadIdx.x;
+    __shared__ int s_last;
+    const int k = blockIdx.x * NB_LUT_MIN + threadIdx.x;
     const float r2max = __uint_as_float(tab->r2max_bits);
     const float tmin = (eps2 < min_val) ? min_val : eps2;        // diagonal entries: r2 == eps2
     const float tmax = (r2max < min_val) ? min_val : r2max;
@@ -638,8 +641,15 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
         }
         tab->thr[k] = thr;
     }
-    __syncthreads();               // every thread has read tab->r2max_bits
-    if (k == 0 && ps) {
+    __syncthreads();               // every thread of this block has read tab->r2max_bits and written its entry
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = (atomicAdd(&tab->blocks_done, 1u) == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const bool fin = threadIdx.x == 0;
+    if (fin && ps) {
         // the pruned max-r2 search is finished: reset its scratch for the next evaluation
         for (int c = 0; c < 3; ++c) { ps->box_min[c] = 0xffffffffu; ps->box_max[c] = 0u; }
         ps->far = 0ull;
@@ -648,7 +658,8 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
         ps->count = 0;
         ps->nan_flag = 0;
     }
-    if (k == 0) {
+    if (fin) {
+        tab->blocks_done = 0u;
         // sentinel above the last bin: NaN compares false, so a lookup can never step past L-1
         tab->thr[levels] = __builtin_nanf("");
         // fast bin estimate for the pair loop: n ~ log2(r2) * a + b with a = ln2*(L-1)/range.
@@ -733,19 +744,22 @@ hipError_t nb_launch_force_f64(const double *pos, const double *mass, double *pa
 }
 
 hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *partial, const ForceGeom &g,
-                               int dim, int hook, int pa, float G, float eps2, const GridTables *tab, hipStream_t st)
+                               int dim, int hook, int pa, float G, float eps2, const GridTables *tab, int levels,
+                               hipStream_t st)
 {
+    const int lp = hook == HOOK_GRID ? nb_lut_pad(levels) : 0;
+    const size_t lds = hook == HOOK_GRID ? nb_lut_lds_bytes(levels) : 0;
     // small systems are parallelism-bound: one target per thread doubles the workgroups (like the fp64 kernel)
     const int r = g.n <= 8192 ? 1 : R_F32;
     const dim3 grid((g.n + NB_BLOCK * r - 1) / (NB_BLOCK * r), g.nchunks);
-#define NB_F32K(DD, HH, LL, PP)                                                                                          \
+#define NB_F32K(DD, HH, PP)                                                                                              \
     do {                                                                                                                 \
         if (r == 1)                                                                                                      \
-            hipLaunchKernelGGL((force_f32_kernel<DD, 1, HH, LL, PP>), grid, dim3(NB_BLOCK), 0, st, pos, mass, partial, g, \
-                               G, eps2, tab);                                                                            \
+            hipLaunchKernelGGL((force_f32_kernel<DD, 1, HH, PP>), grid, dim3(NB_BLOCK), lds, st, pos, mass, partial, g,  \
+                               G, eps2, tab, lp);                                                                        \
         else                                                                                                             \
-            hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HH, LL, PP>), grid, dim3(NB_BLOCK), 0, st, pos, mass, partial, \
-                               g, G, eps2, tab);                                                                         \
+            hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HH, PP>), grid, dim3(NB_BLOCK), lds, st, pos, mass, partial, \
+                               g, G, eps2, tab, lp);                                                                     \
     } while (0)
     return dispatch_dim(dim, [&](auto D) {
         constexpr int DD = decltype(D)::value;
@@ -753,21 +767,21 @@ hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *part
             // half-typed state: cast hooks only (a grid over a half tensor is not implemented)
             if (hook == HOOK_GRID) return hipErrorInvalidValue;
             if (pa == NB_F16) {
-                if (hook == HOOK_NONE) NB_F32K(DD, HOOK_NONE, 1, NB_F16);
-                else if (hook == HOOK_BF16) NB_F32K(DD, HOOK_BF16, 1, NB_F16);
-                else NB_F32K(DD, HOOK_F16, 1, NB_F16);
+                if (hook == HOOK_NONE) NB_F32K(DD, HOOK_NONE, NB_F16);
+                else if (hook == HOOK_BF16) NB_F32K(DD, HOOK_BF16, NB_F16);
+                else NB_F32K(DD, HOOK_F16, NB_F16);
             } else {
-                if (hook == HOOK_NONE) NB_F32K(DD, HOOK_NONE, 1, NB_BF16);
-                else if (hook == HOOK_BF16) NB_F32K(DD, HOOK_BF16, 1, NB_BF16);
-                else NB_F32K(DD, HOOK_F16, 1, NB_BF16);
+                if (hook == HOOK_NONE) NB_F32K(DD, HOOK_NONE, NB_BF16);
+                else if (hook == HOOK_BF16) NB_F32K(DD, HOOK_BF16, NB_BF16);
+                else NB_F32K(DD, HOOK_F16, NB_BF16);
             }
             return hipGetLastError();
         }
         switch (hook) {
-        case HOOK_NONE: NB_F32K(DD, HOOK_NONE, 1, NB_F32); break;
-        case HOOK_BF16: NB_F32K(DD, HOOK_BF16, 1, NB_F32); break;
-        case HOOK_F16: NB_F32K(DD, HOOK_F16, 1, NB_F32); break;
-        case HOOK_GRID: NB_F32K(DD, HOOK_GRID, NB_MAX_LUT, NB_F32); break;
+        case HOOK_NONE: NB_F32K(DD, HOOK_NONE, NB_F32); break;
+        case HOOK_BF16: NB_F32K(DD, HOOK_BF16, NB_F32); break;
+        case HOOK_F16: NB_F32K(DD, HOOK_F16, NB_F32); break;
+        case HOOK_GRID: NB_F32K(DD, HOOK_GRID, NB_F32); break;
         default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
@@ -812,7 +826,8 @@ hipError_t nb_launch_r2max_pruned(const float *pos, int n, int dim, float eps2, 
 hipError_t nb_launch_grid_tables(GridTables *tab, int levels, float G, float eps2, float min_val, PruneState *ps,
                                  hipStream_t st)
 {
-    hipLaunchKernelGGL(grid_tables_kernel, dim3(1), dim3(NB_MAX_LUT), 0, st, tab, levels, G, eps2, min_val, ps);
+    hipLaunchKernelGGL(grid_tables_kernel, dim3((levels + NB_LUT_MIN - 1) / NB_LUT_MIN), dim3(NB_LUT_MIN), 0, st, tab,
+                       levels, G, eps2, min_val, ps);
     return hipGetLastError();
 }
 

@@ -88,6 +88,7 @@ struct GridArgs {
     float est_a, est_b, gfac;
     int lmax_bin;
     bool degenerate;
+    int lp;                 // table size (power of two) for the binary-search fallback
 };
 
 // One sweep of a target tile (R particles per lane) against RJ source slots: `nsteps` rotation steps (64 = all
@@ -149,7 +150,7 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
                         } else if (EST == 2) {
                             w = ga.lut[grid_bin_floor_estimate(ga.thr, r2, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
                         } else {
-                            w = ga.lut[grid_bin_lookup<NB_MAX_LUT>(ga.thr, r2)];   // (1/q^1.5)*G
+                            w = ga.lut[grid_bin_lookup(ga.thr, r2, ga.lp)];   // (1/q^1.5)*G
                         }
                     } else {
                         float q = r2;
@@ -225,8 +226,8 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                         w.x = ga.lut[grid_bin_floor_estimate(ga.thr, r2.x, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
                         w.y = ga.lut[grid_bin_floor_estimate(ga.thr, r2.y, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
                     } else {
-                        w.x = ga.lut[grid_bin_lookup<NB_MAX_LUT>(ga.thr, r2.x)];
-                        w.y = ga.lut[grid_bin_lookup<NB_MAX_LUT>(ga.thr, r2.y)];
+                        w.x = ga.lut[grid_bin_lookup(ga.thr, r2.x, ga.lp)];
+                        w.y = ga.lut[grid_bin_lookup(ga.thr, r2.y, ga.lp)];
                     }
                 } else {
                     f2 q = r2;
@@ -268,8 +269,8 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
 // rowslab [slot][D][B] fp64 (one target tile per workgroup slot), colslab [row][D][NP] of T.
 // <= 128 VGPRs: four waves per SIMD.  (Five waves -- 96 VGPRs -- were measured too: no gain at any
 // shard count, and the general-mass kernel starts to spill.)
-template <typename T, int D, int R, bool UNIFORM, int HOOK>
-__global__ void __launch_bounds__(NB_BLOCK, 4)
+template <typename T, int D, int R, bool UNIFORM, int HOOK, int LPC = NB_LUT_MIN>
+__global__ void __launch_bounds__(NB_BLOCK, (HOOK == HOOK_GRID && LPC > NB_LUT_MIN) ? 3 : 4)
 force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work, double *__restrict__ rowslab,
                  T *__restrict__ colslab, int np, T eps2, const GridTables *__restrict__ tab, float gfac, int gate)
 {
@@ -278,15 +279,19 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
     constexpr int W = NB_BLOCK / 64;
     constexpr bool F32 = std::is_same_v<T, float>;
     __shared__ T s_aj[W][RJ][D][64];
-    __shared__ float s_thr[HOOK == HOOK_GRID ? NB_MAX_LUT + 1 : 1];
-    __shared__ float s_lut[HOOK == HOOK_GRID ? NB_MAX_LUT + 1 : 1];
-    __shared__ float4 s_rec[HOOK == HOOK_GRID ? NB_MAX_LUT : 1];
+    // grid hook: threshold and LUT tables with compile-time offsets (a run-time table base costs an address add per
+    // lookup: +4..8 % on the INT8 / CUSTOM kernels).  LPC = 256 serves INT8 / INT4 / CUSTOM <= 256, LPC = NB_MAX_LUT
+    // the larger CUSTOM grids (33 KB: three workgroups per CU instead of four).
+    constexpr int lp = LPC;
+    __shared__ float s_thr[HOOK == HOOK_GRID ? LPC + 1 : 1];
+    __shared__ float s_lut[HOOK == HOOK_GRID ? LPC + 1 : 1];
+    __shared__ float4 s_rec[HOOK == HOOK_GRID ? NB_REC_LEVELS + 1 : 1];
 
     const SymWork wk = work[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int I = wk.tile_i + wave;             // this wave's target tile (wave-uniform)
     const int rot_addr = ((lane + 1) & 63) << 2;
-    GridArgs ga{s_thr, s_lut, s_rec, 0.0f, 0.0f, gfac, 0, false};
+    GridArgs ga{s_thr, s_lut, s_rec, 0.0f, 0.0f, gfac, 0, false, lp};
     bool use_est = false, few_levels = false;
     if (HOOK == HOOK_GRID) {
         const int levels = tab->levels;
@@ -298,7 +303,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
         // per pair).  More levels: random 16-byte reads saturate the LDS, two dependent 4-byte reads
         // (threshold, then LUT value) are cheaper.
         few_levels = levels <= NB_REC_LEVELS;
-        for (int k = threadIdx.x; k <= NB_MAX_LUT; k += NB_BLOCK) {
+        for (int k = threadIdx.x; k <= lp; k += NB_BLOCK) {
             // binary search pads with +inf; the estimate path needs the NaN sentinel at thr[levels]
             s_thr[k] = (k <= levels) ? tab->thr[k] : __builtin_inff();
             // uniform masses: padding particles (r2 >= 1e36) are caught by one more "bin" of weight 0
@@ -311,7 +316,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
         ga.lmax_bin = UNIFORM ? levels : levels - 1;
         use_est = tab->use_est != 0;
         __syncthreads();
-        for (int k = threadIdx.x; k < NB_MAX_LUT; k += NB_BLOCK)
+        for (int k = threadIdx.x; k <= NB_REC_LEVELS; k += NB_BLOCK)     // lp >= NB_LUT_MIN > NB_REC_LEVELS + 1
             s_rec[k] = make_float4(s_thr[k + 1], s_lut[k], s_lut[k + 1], 0.0f);
         __syncthreads();
     }
@@ -644,25 +649,39 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
     }
 }
 
-template <typename T, int D, int R, int HOOK>
-hipError_t launch_sym_u(const T *packed, const SymWork *work, int nwork, double *rowslab, T *colslab, int np,
-                        int uniform, T eps2, const GridTables *tab, float gfac, hipStream_t st, NbKernelEvents ev,
-                        float mass_value = 0.0f)
+template <typename T, int D, int R, int HOOK, int LPC>
+hipError_t launch_sym_lpc(const T *packed, const SymWork *work, int nwork, double *rowslab, T *colslab, int np,
+                          int uniform, T eps2, const GridTables *tab, float gfac, hipStream_t st, NbKernelEvents ev,
+                          float mass_value)
 {
     if (uniform && HOOK == HOOK_GRID) {
         // uniform-mass grid kernel, valid only while the tables say so (GridTables::uniform_ok, known on the
         // device only): launch it together with the general kernel, exactly one of the two does the work
-        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
+        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK, LPC>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
                               nullptr, 0, packed, work, rowslab, colslab, np, eps2, tab, mass_value, 1);
-        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, nullptr,
+        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK, LPC>), dim3(nwork), dim3(NB_BLOCK), 0, st, nullptr,
                               ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 2);
     } else if (uniform)
-        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
+        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK, LPC>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
                               ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 0);
     else
-        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
+        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK, LPC>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
                               ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 0);
     return hipGetLastError();
+}
+
+template <typename T, int D, int R, int HOOK>
+hipError_t launch_sym_u(const T *packed, const SymWork *work, int nwork, double *rowslab, T *colslab, int np,
+                        int uniform, T eps2, const GridTables *tab, float gfac, hipStream_t st, NbKernelEvents ev,
+                        float mass_value = 0.0f, int levels = 0)
+{
+    if constexpr (HOOK == HOOK_GRID) {
+        if (levels > NB_LUT_MIN)
+            return launch_sym_lpc<T, D, R, HOOK, NB_MAX_LUT>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab,
+                                                             gfac, st, ev, mass_value);
+    }
+    return launch_sym_lpc<T, D, R, HOOK, NB_LUT_MIN>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, gfac,
+                                                     st, ev, mass_value);
 }
 
 }  // namespace
@@ -709,14 +728,15 @@ hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, in
 
 hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int nwork, double *rowslab,
                                    float *colslab, int np, int dim, int r, int uniform, int hook, float eps2,
-                                   const GridTables *tab, float G, float mass_value, hipStream_t st, NbKernelEvents ev)
+                                   const GridTables *tab, float G, float mass_value, int levels, hipStream_t st,
+                                   NbKernelEvents ev)
 {
 #define NB_SYM32(DD, RR)                                                                                              \
     switch (hook) {                                                                                                   \
     case HOOK_NONE: return launch_sym_u<float, DD, RR, HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st, ev); \
     case HOOK_BF16: return launch_sym_u<float, DD, RR, HOOK_BF16>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st, ev); \
     case HOOK_F16: return launch_sym_u<float, DD, RR, HOOK_F16>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st, ev);   \
-    case HOOK_GRID: return launch_sym_u<float, DD, RR, HOOK_GRID>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st, ev, mass_value); \
+    case HOOK_GRID: return launch_sym_u<float, DD, RR, HOOK_GRID>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, G, st, ev, mass_value, levels); \
     default: return hipErrorInvalidValue;                                                                             \
     }
     if (dim == 2 && r == 2) { NB_SYM32(2, 2) }

@@ -9,7 +9,8 @@
 // ---- launch geometry ---------------------------------------------------------------------
 constexpr int NB_BLOCK = 256;   // 4 wavefronts of 64
 constexpr int NB_TJ = 256;      // sources staged in LDS per tile (one per thread)
-constexpr int NB_MAX_LUT = 256; // grid levels served by the LDS threshold table
+constexpr int NB_MAX_LUT = 4096; // grid levels served by the threshold tables (LDS: 8 bytes per level, sized per launch)
+constexpr int NB_LUT_MIN = 256;   // smallest table allocation (INT8); tables are padded to a power of two
 #ifndef NB_REC_LEVELS
 #define NB_REC_LEVELS 32         // up to this many levels the pair loop reads one 16-byte record per pair
 #endif
@@ -30,9 +31,20 @@ struct GridTables {
     int degenerate;          // 1: lmax-lmin < 1e-10 -> values pass through clamped
     int levels;
     unsigned int r2max_bits; // atomicMax target (positive floats order as unsigned ints)
+    unsigned int blocks_done; // grid_tables_kernel: arrival counter of its blocks (the last one finalises)
     int uniform_ok;          // 1: the uniform-mass grid kernel may run (estimate usable, r2max far below the
                              //    padding distance, so "r2 >= 1e35" identifies padding particles)
 };
+
+// table entries allocated in LDS for `levels` grid levels: next power of two, at least NB_LUT_MIN (the binary-search
+// fallback walks a power-of-two table padded with +inf)
+inline int nb_lut_pad(int levels)
+{
+    int p = NB_LUT_MIN;
+    while (p < levels) p <<= 1;
+    return p;
+}
+inline size_t nb_lut_lds_bytes(int levels) { return 2 * (size_t)(nb_lut_pad(levels) + 1) * sizeof(float); }
 
 // Scratch of the pruned max-r2 search (nb_force.hip "K2 with pruning").
 struct PruneState {
@@ -82,7 +94,7 @@ hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, in
                                    hipStream_t st, NbKernelEvents ev = {});
 hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int nwork, double *rowslab,
                                    float *colslab, int np, int dim, int r, int uniform, int hook, float eps2,
-                                   const GridTables *tab, float G, float mass_value, hipStream_t st,
+                                   const GridTables *tab, float G, float mass_value, int levels, hipStream_t st,
                                    NbKernelEvents ev = {});
 hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int nwork, double *part, int np, int dim,
                                    int r, int is_f64, int f32_terms, int mass_f32, double eps2, hipStream_t st);
@@ -103,7 +115,7 @@ hipError_t nb_launch_force_f64(const double *pos, const double *mass, double *pa
                                int dim, int pair_dt, int qhook, double G, double eps2_py, float eps2_pair,
                                hipStream_t st);
 hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *partial, const ForceGeom &g,
-                               int dim, int hook, int pa, float G, float eps2, const GridTables *tab,
+                               int dim, int hook, int pa, float G, float eps2, const GridTables *tab, int levels,
                                hipStream_t st);
 hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float eps2, GridTables *tab,
                            hipStream_t st);

@@ -102,7 +102,7 @@ def test_steps_and_energies_vs_reference(nb, fname, mode):
         assert abs(sim.get_potential_energy() - pe) <= 1e-12 * abs(pe)
 
 
-@pytest.mark.parametrize("L", [4, 64])
+@pytest.mark.parametrize("L", [4, 64, 1000])
 def test_custom_levels_native(nb, L):
     """CUSTOM levels natively == the subclass-override sweep idiom of the reference (no force quant)."""
     g = load_golden("g1c_custom_levels.npz")
@@ -1008,3 +1008,29 @@ def test_grid_modes_trajectory_on_symmetric_path(nb, mode):
     assert relerr(sim.positions.numpy(), ref.positions) < 2e-6
     e, e_ref = sim.get_total_energy(), ref.get_total_energy()
     assert abs(e - e_ref) <= 2e-5 * abs(e_ref)
+
+
+@pytest.mark.parametrize("L,sym", [(512, 0), (1000, 1), (4096, 0), (4096, 1)])
+def test_custom_levels_above_256_bins(nb, monkeypatch, L, sym):
+    """sensitivity_test.py sweeps 512 / 1024 / 4096 levels: the fused path serves up to 4096 (tables sized per
+    launch).  Every distance bin and lmax against the oracle, one-sided and symmetric kernels, then a short
+    trajectory; more levels than that fail loudly."""
+    from oracle import oracle as O
+    monkeypatch.setenv("NB_SYM", str(sym))
+    rng = np.random.default_rng(L + sym)
+    n = 900
+    pos = (rng.standard_normal((n, 2)) * 6).astype(np.float32)
+    vel = (rng.standard_normal((n, 2)) * 0.05).astype(np.float32)
+    mass = (np.ones(n) if sym else 0.5 + rng.random(n)).astype(np.float32)
+    sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode.CUSTOM, custom_levels=L)
+    ref, dbg = O.accelerations(pos, mass, "custom", levels=L, debug=True)
+    got = sim.quant_debug(bins=True)
+    assert np.float32(got["lmax"]) == np.float32(dbg["lmax"])
+    assert np.array_equal(got["d2bins"], dbg["d2bins"])
+    assert relerr(sim.accelerations.numpy(), ref) < 3e-6
+    o = O.OracleSim(pos, vel, mass, "custom", levels=L)
+    sim.run(3)
+    o.run(3)
+    assert relerr(sim.positions.numpy(), o.positions) < 1e-5
+    with pytest.raises(RuntimeError):
+        nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode.CUSTOM, custom_levels=5000)
