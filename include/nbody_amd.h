@@ -55,7 +55,7 @@ typedef struct nb_config {
     int32_t n;             /* num_stars                                                     */
     int32_t dim;           /* 2 or 3 (positions are (n, dim) row-major)                     */
     int32_t mode;          /* nb_mode                                                       */
-    int32_t levels;        /* CUSTOM grid levels; 0 -> 64 (quantization.py:66)              */
+    int32_t levels;        /* CUSTOM grid levels, 2..4096 fused; 0 -> 64 (quantization.py:66) */
     double  G;             /* gravitational constant                                        */
     double  softening_sq;  /* softening**2 evaluated in Python double (simulation.py:59)    */
     double  dt;            /* time step                                                     */
