@@ -205,11 +205,17 @@ int build_sym_plan(nb_sim *s)
     auto &sp = s->sym;
     sp.enabled = false;
     const nb_config &c = s->cfg;
-    // Below ~10 k particles the pair-symmetric kernel has too few work items to fill the chip (one
-    // 64-step sweep per wave is its floor: ~53 us per step at any N <= 8192) and the one-sided LDS kernel
-    // wins (measured fp64, us per step, one-sided / symmetric: N = 4096 22.6 / 53.3, 8192 48.7 / 54.7,
-    // 12288 90.6 / 83.4, 16384 149 / 118).
-    int want = (c.n > 8192) ? 1 : 0;
+    // Small systems: the pair-symmetric kernel has too few work items to fill the chip (one 64-step sweep per
+    // wave is its floor: ~50 us per step with tiles of 256 at any N <= 8192) and the one-sided LDS kernel wins.
+    // Between the two regimes a finer tiling (R = 2: tiles of 128, four times the work items, sweeps a quarter
+    // as long) fills the chip earlier: measured fp64 us per step, one-sided / R = 2 / R = 4: N = 6144 38.9 / 30.8 /
+    // 51.5, 8192 47.4 / 44.5 / 52.1, 12288 113 / 66.5 / 81.0, 16384 149 / 107 / 118, 20480 - / 154 / 152, 32768 - /
+    // 366 / 310; fp32: N = 4096 18.6 / 16.1 / 37.0, 8192 40.2 / 26.4 / 38.3, 16384 118 / 61.4 / 70.8, 24576 269 / 118 / 105.
+    // And at the very small end (fp64, 2-D) tiles of 64 (R = 1: one 64-step sweep of single pairs per wave, ~4 us)
+    // beat the one-sided kernel: 12.1 vs 16.6 us per step at N = 1024, 13.1 vs 18.3 at 2560, 18.1 vs 18.7 at 3000.
+    const bool tiny = s->is_f64 && c.dim == 2 && c.n <= 2816;
+    const int sym_from = s->is_f64 ? 5120 : 4096;
+    int want = (tiny || c.n >= sym_from) ? 1 : 0;
     if (const char *e = getenv("NB_SYM")) want = atoi(e);
     // comm-less shards (NB_FLAG_NO_COMM) use the one-sided kernel unless NB_SYM=2 asks for the symmetric
     // plan of their rank (tests: the partial sums of all ranks' plans must add up to the full result)
@@ -217,7 +223,7 @@ int build_sym_plan(nb_sim *s)
     if (s->is_f64 && c.mode != NB_FLOAT64) return NB_OK;    // fp64 state under a cast mode: one-sided kernel
     // targets per lane.  Measured on MI355X, N=65536, D=2: R=1 3.39 ms, R=2 1.87 ms, R=4 1.47 ms.  D=3 also keeps
     // four targets per lane and sweeps the source tile in two halves of two slots (sym_rj, nb_force_sym.hip)
-    sp.r = 4;
+    sp.r = tiny ? 1 : (c.n < 20480) ? 2 : 4;
     if (const char *e = getenv("NB_SYM_R")) {
         const int r = atoi(e);
         if ((r == 1 && s->is_f64 && c.dim == 2) || r == 2 || r == 4) sp.r = r;
@@ -491,7 +497,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
             return fail(NB_ERR_UNSUPPORTED, "mixed fp32 positions in fp64 storage under a cast mode");
         const int pair_dt = (qhook < 0 && s->logical[0] != NB_F64) ? s->logical[0] : -1;   // NB_F32 / F16 / BF16
         const int pa_f32 = (pair_dt == NB_F32);
-        const bool sym_default_shape = s->sym.r == 4 || (c.dim == 3 && s->sym.r == 2);   // HOOK_F32PAIR instantiations
+        const bool sym_default_shape = s->sym.r == 4 || s->sym.r == 2;   // HOOK_F32PAIR instantiations
         used_sym = s->sym.enabled && qhook < 0 && (pair_dt < 0 || (pa_f32 && sym_default_shape));
         sym_uniform = s->mass_uniform;
         if (used_sym) {

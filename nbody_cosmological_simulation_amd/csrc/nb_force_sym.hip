@@ -713,6 +713,7 @@ hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, in
     if (pa_f32) {   // first evaluation on fp32-typed positions: default tile shapes only
         const float e32 = (float)eps2;
         if (dim == 2 && r == 4) return launch_sym_u<double, 2, 4, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st, ev);
+        if (dim == 2 && r == 2) return launch_sym_u<double, 2, 2, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st, ev);
         if (dim == 3 && r == 2) return launch_sym_u<double, 3, 2, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st, ev);
         if (dim == 3 && r == 4) return launch_sym_u<double, 3, 4, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st, ev);
         return hipErrorInvalidValue;
