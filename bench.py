@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000, help="timed steps (default: the 2 000 ticks of BASELINE config 2)")
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--n", type=int, default=65536, help="particles (default: BASELINE config 2)")
+    ap.add_argument("--n", "--particles", dest="n", type=int, default=65536,
+                    help="particles (default: BASELINE config 2); use --particles under torch.distributed.run, whose\n"
+                         "own parser takes --n for an abbreviation of --nnodes")
     ap.add_argument("--mode", default="float64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample length")
