@@ -561,7 +561,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
             // grid LUT already carries G (simulation.py:101), so the packed factor is the bare mass there
             sym_uniform = s->mass_uniform && hook != HOOK_GRID;
             const double gfac = (hook == HOOK_GRID) ? 1.0 : (double)(float)c.G;
-            if (!packed_ready || hook == HOOK_GRID)
+            if (!packed_ready)
                 HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, 0, 0, 0.0, 0.0,
                                       gfac, 0, s->stream));
             if (int rc = prof_begin(s, &slot, false)) return rc;
@@ -589,9 +589,8 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         // uniform-mass kernels leave out the mass factor: G*m in T arithmetic (fp32: (float)G * m)
         double scale = 1.0;
         if (sym_uniform) scale = s->is_f64 ? c.G * s->mass_value : (double)((float)c.G * (float)s->mass_value);
-        // inside nb_step the reduction also opens the next step and repacks its positions (packed_ready says
-        // the fused pack flow is in use: uniform dtypes, no grid hook)
-        const bool open = fuse_kick && want_open && packed_ready;
+        // inside nb_step the reduction also opens the next step and repacks its positions
+        const bool open = fuse_kick && want_open;
         HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.col_upto,
                                     sp.tile_b, c.n, sp.np, c.dim, s->is_f64, scale, s->acc, s->vel, half_dt,
                                     open ? 2 : (fuse_kick ? 1 : 0), s->pos, sp.packed, c.dt, s->stream));
@@ -614,7 +613,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         const bool open = want_open;
         HIPCHK(nb_launch_force_quant_step((float *)s->acc, cnt, mode_levels(c), s->scalars, s->scalars + 8, s->fbins,
                                           (float *)s->vel, (float *)s->pos, half_dt, c.dt, do_kick ? (open ? 2 : 1) : 0,
-                                          s->stream));
+                                          used_sym ? (float *)s->sym.packed : nullptr, s->sym.np, c.dim, s->stream));
         kicked = do_kick;
         opened = open;
     }
@@ -808,6 +807,7 @@ int nb_step(nb_sim *s, int32_t nsteps)
     DeviceGuard guard(s->cfg.device);
     bool pending_close = false;     // closing kick of the previous step still to be applied
     bool opened = false;            // the previous step's reduction already did this step's opening kick + drift
+    bool packed_by_prev = false;    // ... and repacked the positions for the symmetric kernel
     for (int t = 0; t < nsteps; ++t) {
         // opening kick + drift; on the pair-symmetric path the repack rides in the same launch
         const int sdt = s->is_f64 ? NB_F64 : NB_F32;
@@ -824,15 +824,18 @@ int nb_step(nb_sim *s, int32_t nsteps)
             if (pending_close) HIPCHK(nb_launch_axpy(s->vel, s->acc, s->cfg.dt / 2, nd(s), s->is_f64, s->stream));
             HIPCHK(nb_launch_kick_drift(s->pos, s->vel, s->acc, s->cfg.dt / 2, s->cfg.dt, nd(s), s->is_f64, s->stream));
         }
+        // packed positions are current when this step's pack launch wrote them, or when the previous evaluation
+        // opened this step on the symmetric path (its reduction / quantisation repacked them)
+        const bool packed_ready = opened ? packed_by_prev : fuse_pack;
         pending_close = false;
         s->logical[1] = promote(s->logical[1], s->logical[3]);
         s->logical[0] = promote(s->logical[0], s->logical[1]);
         // a closing kick that cannot ride in the reduction (RCCL all-reduce / force quantisation in
         // between) is folded into the next step's opening launch when there is one
         const bool may_defer = (t + 1 < nsteps) && fuse_pack;
-        opened = (t + 1 < nsteps) && uniform_dt &&
-                 (!s->sym.enabled || force_quant_mode(s->cfg) || fuse_pack);   // request; force_eval answers
-        if (int rc = force_eval(s, true, fuse_pack, may_defer ? &pending_close : nullptr, &opened)) return rc;
+        opened = (t + 1 < nsteps) && uniform_dt;      // request; force_eval answers
+        if (int rc = force_eval(s, true, packed_ready, may_defer ? &pending_close : nullptr, &opened)) return rc;
+        packed_by_prev = opened && s->sym.enabled;
         s->logical[1] = promote(s->logical[1], s->logical[3]);
     }
     return NB_OK;

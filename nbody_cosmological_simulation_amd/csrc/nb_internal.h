@@ -141,7 +141,8 @@ hipError_t nb_launch_convert(const void *in, int in_dt, void *out, int out_dt, i
 hipError_t nb_launch_force_quant_step(float *acc, int64_t count, int levels, double *mn_mx, double *partials,
                                       int16_t *bins, float *vel, float *pos, double half_dt, double dt,
                                       int kick /* 0 none, 1 closing kick, 2 + next opening kick + drift */,
-                                      hipStream_t st);
+                                      float *packed /* symmetric path: also repack the new positions, else null */,
+                                      int np, int dim, hipStream_t st);
 hipError_t nb_launch_force_quant_bins(const float *in, float *out, int64_t count, int levels, const double *mn_mx,
                                       int16_t *bins, hipStream_t st);
 

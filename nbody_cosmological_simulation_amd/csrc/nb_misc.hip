@@ -215,7 +215,8 @@ grid_quantize_kernel(const T *in, T *out /* may alias in */, int64_t count, int 
 __global__ void __launch_bounds__(256)
 force_quant_finish_kernel(float *__restrict__ acc, int64_t count, int levels, const double *__restrict__ partials,
                           int nblocks, double *__restrict__ mn_mx, int16_t *__restrict__ bins, float *__restrict__ vel,
-                          float *__restrict__ pos, float half_dt, float dt, int kick)
+                          float *__restrict__ pos, float half_dt, float dt, int kick, float *__restrict__ packed, int np,
+                          int dim)
 {
     __shared__ double s_mn[4], s_mx[4];
     __shared__ double s_out[2];
@@ -245,7 +246,10 @@ force_quant_finish_kernel(float *__restrict__ acc, int64_t count, int levels, co
             float v = axpy1(vel[idx], a, half_dt);
             if (kick == 2) {
                 v = axpy1(v, a, half_dt);
-                pos[idx] = axpy1(pos[idx], v, dt);
+                const float x = axpy1(pos[idx], v, dt);
+                pos[idx] = x;
+                // pair-symmetric path: the next evaluation's packed positions (component arrays) in the same pass
+                if (packed) packed[(size_t)(idx % dim) * np + idx / dim] = x;
             }
             vel[idx] = v;
         }
@@ -530,7 +534,7 @@ hipError_t nb_launch_force_quant_bins(const float *in, float *out, int64_t count
 // min/max of the summed forces + quantisation (+ kicks) of the step: two launches
 hipError_t nb_launch_force_quant_step(float *acc, int64_t count, int levels, double *mn_mx, double *partials,
                                       int16_t *bins, float *vel, float *pos, double half_dt, double dt, int kick,
-                                      hipStream_t st)
+                                      float *packed, int np, int dim, hipStream_t st)
 {
     int blocks = (int)((count + 1023) / 1024);
     blocks = blocks < 1 ? 1 : (blocks > MM_BLOCKS ? MM_BLOCKS : blocks);
@@ -539,7 +543,7 @@ hipError_t nb_launch_force_quant_step(float *acc, int64_t count, int levels, dou
     int grid = (int)((count + 255) / 256);
     grid = grid > 2048 ? 2048 : grid;
     hipLaunchKernelGGL(force_quant_finish_kernel, dim3(grid), dim3(256), 0, st, acc, count, levels, partials, blocks,
-                       mn_mx, bins, vel, pos, (float)half_dt, (float)dt, kick);
+                       mn_mx, bins, vel, pos, (float)half_dt, (float)dt, kick, packed, np, dim);
     return hipGetLastError();
 }
 
