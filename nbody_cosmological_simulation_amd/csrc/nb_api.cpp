@@ -864,11 +864,11 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential)
             HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, s->is_f64, 0, 0.0, 0.0,
                                   1.0, s->is_f64 && s->logical[0] != NB_F64, s->stream));
             HIPCHK(nb_launch_potential_sym(sp.packed, sp.work, sp.nwork, s->scratch, sp.np, c.dim, sp.r, s->is_f64,
-                                           s->logical[0] != NB_F64, s->logical[2] != NB_F64, c.softening_sq, s->stream));
+                                           s->logical[0] != NB_F64, s->logical[2], c.softening_sq, s->stream));
             HIPCHK(nb_launch_final_sum(s->scratch, sp.nwork, s->scalars + 3, s->stream));
         } else {
             HIPCHK(nb_launch_potential(s->pos, s->mass, s->geom, c.dim, s->is_f64, s->logical[0] != NB_F64,
-                                       s->logical[2] != NB_F64, hp_x, c.softening_sq,
+                                       s->logical[2], hp_x, c.softening_sq,
                                        (float)round_dt(hp_x >= 0 ? hp_x : NB_F32, c.softening_sq), s->scratch,
                                        s->scalars + 3, s->stream));
         }

@@ -7,6 +7,17 @@ namespace nbdev {
 __device__ __forceinline__ float round_bf16(float x) { return (float)(__bf16)x; }
 __device__ __forceinline__ float round_f16(float x) { return (float)(_Float16)x; }
 
+// mass_prod = masses[i] * masses[j] keeps the masses' dtype upstream (simulation.py:185): fp32-typed masses give an
+// fp32-rounded product even when the positions are fp64, half-typed masses (omega_point_test.py:722-733 keeps them
+// half while the rest of the state is promoted) a product rounded to that half type.  mass_dt: nb_dtype of the masses.
+__device__ __forceinline__ float mass_prod_f32(float mi, float mj, int mass_dt)
+{
+    float p = __fmul_rn(mi, mj);                       // exact for half inputs (11 + 11 bits)
+    if (mass_dt == NB_F16) p = (float)(_Float16)p;
+    else if (mass_dt == NB_BF16) p = (float)(__bf16)p;
+    return p;
+}
+
 // r2 exactly as the reference's fp32 tensors produce it: (dx*dx + dy*dy [+ dz*dz]) + eps2, one
 // rounding per operation, no fused multiply-add (simulation.py:86).
 template <int D>

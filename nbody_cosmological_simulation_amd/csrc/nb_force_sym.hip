@@ -559,7 +559,7 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
 template <typename T, int D, int R, bool F32T>
 __global__ void __launch_bounds__(NB_BLOCK)
 potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work, double *__restrict__ part,
-                     int np, double eps2, float eps2_f, int mass_f32)
+                     int np, double eps2, float eps2_f, int mass_dt)
 {
     constexpr int B = 64 * R;
     __shared__ double s_red[NB_BLOCK / 64];
@@ -606,7 +606,7 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
                             d2 = (k == 0) ? sq : __fadd_rn(d2, sq);
                         }
                         const float dist = __fsqrt_rn(__fadd_rn(d2, eps2_f));
-                        term = (double)__fdiv_rn(__fmul_rn((float)mi[ri], (float)mj[rj]), dist);
+                        term = (double)__fdiv_rn(mass_prod_f32((float)mi[ri], (float)mj[rj], mass_dt), dist);
                     } else {
                         double q = eps2;
 #pragma unroll
@@ -617,8 +617,8 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
                         const double y0 = __builtin_amdgcn_rsq(q);
                         const double e = __builtin_fma(-q * y0, y0, 1.0);
                         const double y = __builtin_fma(y0 * e, __builtin_fma(e, 0.375, 0.5), y0);
-                        const double mp = mass_f32 ? (double)__fmul_rn((float)mi[ri], (float)mj[rj])
-                                                   : (double)mi[ri] * (double)mj[rj];
+                        const double mp = mass_dt != NB_F64 ? (double)mass_prod_f32((float)mi[ri], (float)mj[rj], mass_dt)
+                                                            : (double)mi[ri] * (double)mj[rj];
                         term = mp * y;
                     }
                     if (ri == rj) term = (diag && s == 0) ? 0.0 : term;     // self pair
@@ -749,12 +749,12 @@ hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int
 }
 
 hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int nwork, double *part, int np, int dim,
-                                   int r, int is_f64, int f32_terms, int mass_f32, double eps2, hipStream_t st)
+                                   int r, int is_f64, int f32_terms, int mass_dt, double eps2, hipStream_t st)
 {
     const float e32 = (float)eps2;
 #define NB_PES(TT, DD, RR, FF) \
     hipLaunchKernelGGL((potential_sym_kernel<TT, DD, RR, FF>), dim3(nwork), dim3(NB_BLOCK), 0, st, (const TT *)packed, \
-                       work, part, np, eps2, e32, mass_f32)
+                       work, part, np, eps2, e32, mass_dt)
     if (is_f64) {
         if (dim == 2 && r == 4) { if (f32_terms) NB_PES(double, 2, 4, true); else NB_PES(double, 2, 4, false); }
         else if (dim == 2 && r == 2) { if (f32_terms) NB_PES(double, 2, 2, true); else NB_PES(double, 2, 2, false); }

@@ -97,7 +97,7 @@ hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int
                                    const GridTables *tab, float G, float mass_value, int levels, hipStream_t st,
                                    NbKernelEvents ev = {});
 hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int nwork, double *part, int np, int dim,
-                                   int r, int is_f64, int f32_terms, int mass_f32, double eps2, hipStream_t st);
+                                   int r, int is_f64, int f32_terms, int mass_dt /* nb_dtype of the masses */, double eps2, hipStream_t st);
 hipError_t nb_launch_final_sum(const double *part, int count, double *out, hipStream_t st);
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
                                 const int *row_nslots, const int *col_upto, int tile_b, int n,
@@ -149,7 +149,7 @@ hipError_t nb_launch_force_quant_bins(const float *in, float *out, int64_t count
 hipError_t nb_launch_kinetic(const void *vel, const void *mass, int n, int dim, int is_f64, int vel_f32_logical,
                              int half_pa, double *scratch, double *out, hipStream_t st);
 hipError_t nb_launch_potential(const void *pos, const void *mass, const ForceGeom &g, int dim, int is_f64,
-                               int pa_f32, int mass_f32, int half_pa, double eps2_py, float eps2_half,
+                               int pa_f32, int mass_dt /* nb_dtype of the masses */, int half_pa, double eps2_py, float eps2_half,
                                double *scratch, double *out, hipStream_t st);
 
 // tensor-level hooks (quantization.py module functions)

@@ -1,7 +1,7 @@
 // nb_misc.hip -- O(N) kernels around the force sum: slab reduction + leapfrog kicks
 // (simulation.py:132-141), dtype conversion, linear force quantisation (quantization.py:74-88),
 // energies (simulation.py:170-192) and the tensor-level precision hooks.  gfx950 only.
-#include "nb_internal.h"
+#include "nb_device.h"
 
 #include <hip/hip_fp16.h>
 
@@ -373,7 +373,7 @@ final_sum_kernel(const double *__restrict__ part, int count, double *__restrict_
 template <typename T, int D, bool PA_F32, int HP = -1>
 __global__ void __launch_bounds__(NB_BLOCK)
 potential_kernel(const T *__restrict__ pos, const T *__restrict__ mass, ForceGeom g, double eps2, float eps2_f,
-                 int mass_f32, double *__restrict__ part)
+                 int mass_dt, double *__restrict__ part)
 {
     __shared__ T sj[D + 1][NB_TJ];
     __shared__ double s_red[NB_BLOCK / 64];
@@ -414,7 +414,7 @@ potential_kernel(const T *__restrict__ pos, const T *__restrict__ mass, ForceGeo
                 }
                 d2 = round_hp<HP>(d2);
                 const float dist = round_hp<HP>(__fsqrt_rn(round_hp<HP>(__fadd_rn(d2, eps2_f))));
-                term = (double)round_hp<HP>(__fdiv_rn(round_hp<HP>(__fmul_rn((float)mi, (float)sj[D][jj])), dist));
+                term = (double)round_hp<HP>(__fdiv_rn(round_hp<HP>(nbdev::mass_prod_f32((float)mi, (float)sj[D][jj], mass_dt)), dist));
             } else {
                 double q = eps2;
 #pragma unroll
@@ -428,8 +428,8 @@ potential_kernel(const T *__restrict__ pos, const T *__restrict__ mass, ForceGeo
                 const double y = __builtin_fma(y0 * e, __builtin_fma(e, 0.375, 0.5), y0);
                 // mass_prod keeps the masses' dtype upstream (simulation.py:185): fp32-typed masses
                 // give an fp32-rounded product even when positions are already fp64
-                const double mp = mass_f32 ? (double)__fmul_rn((float)mi, (float)sj[D][jj])
-                                           : (double)mi * (double)sj[D][jj];
+                const double mp = mass_dt != NB_F64 ? (double)nbdev::mass_prod_f32((float)mi, (float)sj[D][jj], mass_dt)
+                                                    : (double)mi * (double)sj[D][jj];
                 term = mp * y;
             }
             s += take ? term : 0.0;
@@ -620,29 +620,29 @@ hipError_t nb_launch_kinetic(const void *vel, const void *mass, int n, int dim, 
 }
 
 hipError_t nb_launch_potential(const void *pos, const void *mass, const ForceGeom &g, int dim, int is_f64,
-                               int pa_f32, int mass_f32, int half_pa, double eps2_py, float eps2_half,
+                               int pa_f32, int mass_dt, int half_pa, double eps2_py, float eps2_half,
                                double *scratch, double *out, hipStream_t st)
 {
     const dim3 grid((g.n + NB_BLOCK - 1) / NB_BLOCK, g.nchunks);
     const float e32 = (half_pa >= 0) ? eps2_half : (float)eps2_py;
 #define NB_PE(T, D, PA) \
-    hipLaunchKernelGGL((potential_kernel<T, D, PA>), grid, dim3(NB_BLOCK), 0, st, (const T *)pos, (const T *)mass, g, eps2_py, e32, mass_f32, scratch)
+    hipLaunchKernelGGL((potential_kernel<T, D, PA>), grid, dim3(NB_BLOCK), 0, st, (const T *)pos, (const T *)mass, g, eps2_py, e32, mass_dt, scratch)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64 && half_pa == NB_F16) {
-        if (dim == 2) hipLaunchKernelGGL((potential_kernel<double, 2, true, NB_F16>), grid, dim3(NB_BLOCK), 0, st, (const double *)pos, (const double *)mass, g, eps2_py, e32, mass_f32, scratch);
-        else hipLaunchKernelGGL((potential_kernel<double, 3, true, NB_F16>), grid, dim3(NB_BLOCK), 0, st, (const double *)pos, (const double *)mass, g, eps2_py, e32, mass_f32, scratch);
+        if (dim == 2) hipLaunchKernelGGL((potential_kernel<double, 2, true, NB_F16>), grid, dim3(NB_BLOCK), 0, st, (const double *)pos, (const double *)mass, g, eps2_py, e32, mass_dt, scratch);
+        else hipLaunchKernelGGL((potential_kernel<double, 3, true, NB_F16>), grid, dim3(NB_BLOCK), 0, st, (const double *)pos, (const double *)mass, g, eps2_py, e32, mass_dt, scratch);
     } else if (is_f64 && half_pa == NB_BF16) {
-        if (dim == 2) hipLaunchKernelGGL((potential_kernel<double, 2, true, NB_BF16>), grid, dim3(NB_BLOCK), 0, st, (const double *)pos, (const double *)mass, g, eps2_py, e32, mass_f32, scratch);
-        else hipLaunchKernelGGL((potential_kernel<double, 3, true, NB_BF16>), grid, dim3(NB_BLOCK), 0, st, (const double *)pos, (const double *)mass, g, eps2_py, e32, mass_f32, scratch);
+        if (dim == 2) hipLaunchKernelGGL((potential_kernel<double, 2, true, NB_BF16>), grid, dim3(NB_BLOCK), 0, st, (const double *)pos, (const double *)mass, g, eps2_py, e32, mass_dt, scratch);
+        else hipLaunchKernelGGL((potential_kernel<double, 3, true, NB_BF16>), grid, dim3(NB_BLOCK), 0, st, (const double *)pos, (const double *)mass, g, eps2_py, e32, mass_dt, scratch);
     } else if (is_f64) {
         if (pa_f32) { if (dim == 2) NB_PE(double, 2, true); else NB_PE(double, 3, true); }
         else        { if (dim == 2) NB_PE(double, 2, false); else NB_PE(double, 3, false); }
     } else if (half_pa == NB_F16) {
-        if (dim == 2) hipLaunchKernelGGL((potential_kernel<float, 2, true, NB_F16>), grid, dim3(NB_BLOCK), 0, st, (const float *)pos, (const float *)mass, g, eps2_py, e32, mass_f32, scratch);
-        else hipLaunchKernelGGL((potential_kernel<float, 3, true, NB_F16>), grid, dim3(NB_BLOCK), 0, st, (const float *)pos, (const float *)mass, g, eps2_py, e32, mass_f32, scratch);
+        if (dim == 2) hipLaunchKernelGGL((potential_kernel<float, 2, true, NB_F16>), grid, dim3(NB_BLOCK), 0, st, (const float *)pos, (const float *)mass, g, eps2_py, e32, mass_dt, scratch);
+        else hipLaunchKernelGGL((potential_kernel<float, 3, true, NB_F16>), grid, dim3(NB_BLOCK), 0, st, (const float *)pos, (const float *)mass, g, eps2_py, e32, mass_dt, scratch);
     } else if (half_pa == NB_BF16) {
-        if (dim == 2) hipLaunchKernelGGL((potential_kernel<float, 2, true, NB_BF16>), grid, dim3(NB_BLOCK), 0, st, (const float *)pos, (const float *)mass, g, eps2_py, e32, mass_f32, scratch);
-        else hipLaunchKernelGGL((potential_kernel<float, 3, true, NB_BF16>), grid, dim3(NB_BLOCK), 0, st, (const float *)pos, (const float *)mass, g, eps2_py, e32, mass_f32, scratch);
+        if (dim == 2) hipLaunchKernelGGL((potential_kernel<float, 2, true, NB_BF16>), grid, dim3(NB_BLOCK), 0, st, (const float *)pos, (const float *)mass, g, eps2_py, e32, mass_dt, scratch);
+        else hipLaunchKernelGGL((potential_kernel<float, 3, true, NB_BF16>), grid, dim3(NB_BLOCK), 0, st, (const float *)pos, (const float *)mass, g, eps2_py, e32, mass_dt, scratch);
     } else {
         if (dim == 2) NB_PE(float, 2, true); else NB_PE(float, 3, true);
     }

@@ -1034,3 +1034,26 @@ def test_custom_levels_above_256_bins(nb, monkeypatch, L, sym):
     assert relerr(sim.positions.numpy(), o.positions) < 1e-5
     with pytest.raises(RuntimeError):
         nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode.CUSTOM, custom_levels=5000)
+
+
+@pytest.mark.parametrize("n", [300, 1500])
+@pytest.mark.parametrize("mode", ["float32", "float16", "float64"])
+def test_half_typed_state_energies_follow_the_masses_dtype(nb, n, mode):
+    """omega_point_test.py:722-733 builds simulations from float16 tensors: positions and velocities are promoted
+    by the first step, the masses stay float16 for good, so `mass_prod` (simulation.py:185) is a float16 product
+    even later on.  Energies before and after the promotion against the oracle's dtype model."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(n)
+    pos = (rng.standard_normal((n, 2)) * 5).astype(np.float16)
+    vel = (rng.standard_normal((n, 2)) * 0.05).astype(np.float16)
+    mass = (0.5 + rng.random(n)).astype(np.float16)
+    sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode(mode))
+    ref = O.OracleSim(pos, vel, mass, mode)
+    for steps in (0, 3):
+        sim.run(steps)
+        ref.run(steps)
+        assert str(sim.masses.dtype) == "torch.float16"
+        for got, want in ((sim.get_kinetic_energy(), ref.get_kinetic_energy()),
+                          (sim.get_potential_energy(), ref.get_potential_energy())):
+            # (float16-typed sums overflow to -inf at N = 1500 before the promotion, on both sides)
+            assert got == want or abs(got - want) <= 2e-7 * abs(want), (steps, got, want)
