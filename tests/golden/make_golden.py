@@ -22,6 +22,9 @@ What is captured:
       override, get_state keys, mode-string alias table.
   G5  tensor-level hooks: quantize_distance_squared / quantize_force / _grid_quantize*
       on random tensors.
+  G6  initial-condition generators and diagnostics (galaxy.py / metrics.py), seeded.
+  G7  half-typed state (float16 / bfloat16 tensors) through the cast modes and FLOAT64: energies before
+      and after the promotion, state after three steps.
 
 Only DATA (inputs + outputs) is stored; no reference source text.
 """
@@ -416,7 +419,31 @@ def g6():
     print("G6")
 
 
+def g7():
+    """Half-typed state (omega_point_test.py:722-733 idiom) through every cast mode: energies before and after the
+    promotion of positions / velocities (the masses stay half for good), state after three steps, dtype timeline."""
+    out = {}
+    for n in (96, 700):
+        pos, vel, mass = make_ics(n, 2, 70 + n, True)
+        for hname, dt_ in (("float16", torch.float16), ("bfloat16", torch.bfloat16)):
+            p, v, m = pos.to(dt_), vel.to(dt_), mass.to(dt_)
+            out[f"n{n}/{hname}/pos"], out[f"n{n}/{hname}/vel"], out[f"n{n}/{hname}/mass"] = npy(p), npy(v), npy(m)
+            for mode in (PrecisionMode.FLOAT32, PrecisionMode.BFLOAT16, PrecisionMode.FLOAT16, PrecisionMode.FLOAT64):
+                sim = ref_sim.GalaxySimulation(p.clone(), v.clone(), m.clone(), precision_mode=mode, G=0.001, dt=0.01,
+                                               softening=0.1)
+                key = f"n{n}/{hname}/{mode.value}"
+                out[key + "/e0"] = np.array([sim.get_kinetic_energy(), sim.get_potential_energy()])
+                for _ in range(3):
+                    sim.step()
+                out[key + "/e3"] = np.array([sim.get_kinetic_energy(), sim.get_potential_energy()])
+                out[key + "/pos3"] = npy(sim.positions).astype(np.float64)
+                out[key + "/vel3"] = npy(sim.velocities).astype(np.float64)
+                out[key + "/dtypes3"] = np.array([str(sim.positions.dtype), str(sim.velocities.dtype),
+                                                  str(sim.accelerations.dtype), str(sim.masses.dtype)])
+    np.savez_compressed(os.path.join(OUT, "g7_half_state.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7"]
     for w in which:
         globals()[w]()

@@ -1057,3 +1057,30 @@ def test_half_typed_state_energies_follow_the_masses_dtype(nb, n, mode):
                           (sim.get_potential_energy(), ref.get_potential_energy())):
             # (float16-typed sums overflow to -inf at N = 1500 before the promotion, on both sides)
             assert got == want or abs(got - want) <= 2e-7 * abs(want), (steps, got, want)
+
+
+@pytest.mark.parametrize("n", [96, 700])
+@pytest.mark.parametrize("hname", ["float16", "bfloat16"])
+@pytest.mark.parametrize("mode", ["float32", "bfloat16", "float16", "float64"])
+def test_half_typed_state_vs_reference_golden(nb, n, hname, mode):
+    """g7: the reference run from float16 / bfloat16 tensors (omega_point_test.py:722-733) in every cast mode and
+    FLOAT64 -- energies before and after the promotion, state and dtypes after three steps."""
+    g = load_golden("g7_half_state.npz")
+    key = f"n{n}/{hname}/{mode}"
+    tdt = getattr(torch, hname)
+    sim = nb.GalaxySimulation(T(g[f"n{n}/{hname}/pos"]).to(tdt), T(g[f"n{n}/{hname}/vel"]).to(tdt),
+                              T(g[f"n{n}/{hname}/mass"]).to(tdt), precision_mode=nb.PrecisionMode(mode))
+
+    def close(got, want, tol):
+        return got == want or abs(got - want) <= tol * abs(want)
+
+    ke0, pe0 = g[key + "/e0"]
+    assert close(sim.get_kinetic_energy(), ke0, 4e-3) and close(sim.get_potential_energy(), pe0, 8e-3)
+    sim.run(3)
+    ke3, pe3 = g[key + "/e3"]
+    tol = 1e-9 if mode == "float64" else 2e-6
+    assert close(sim.get_kinetic_energy(), ke3, tol) and close(sim.get_potential_energy(), pe3, tol)
+    assert relerr(sim.positions.double().numpy(), g[key + "/pos3"]) < (1e-12 if mode == "float64" else 1e-5)
+    assert relerr(sim.velocities.double().numpy(), g[key + "/vel3"]) < (1e-10 if mode == "float64" else 1e-4)
+    assert [str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.accelerations.dtype), str(sim.masses.dtype)] == \
+        list(g[key + "/dtypes3"])

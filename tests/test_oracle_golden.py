@@ -283,3 +283,30 @@ def test_torch_materialised_restatement_agrees(mode):
         assert np.array_equal(st["pos"].numpy(), ref)
     else:
         assert relerr(st["pos"].numpy(), ref) < 1e-6
+
+
+@pytest.mark.parametrize("n", [96, 700])
+@pytest.mark.parametrize("hname,code", [("float16", O.F16), ("bfloat16", O.BF16)])
+@pytest.mark.parametrize("mode", ["float32", "bfloat16", "float16", "float64"])
+def test_g7_half_typed_state(n, hname, code, mode):
+    """Half-typed state through every cast mode and FLOAT64 (reference run, g7): energies before the promotion
+    (half arithmetic, incl. the float16 overflow of the N = 700 potential sum), after it (masses still half:
+    mass products rounded to half, simulation.py:185), and the state after three steps."""
+    g = load_golden("g7_half_state.npz")
+    key = f"n{n}/{hname}/{mode}"
+    sim = O.OracleSim(g[f"n{n}/{hname}/pos"], g[f"n{n}/{hname}/vel"], g[f"n{n}/{hname}/mass"], mode,
+                      codes=(code, code, code))
+
+    def close(got, want, tol):
+        return got == want or abs(got - want) <= tol * abs(want)
+
+    ke0, pe0 = g[key + "/e0"]
+    assert close(sim.get_kinetic_energy(), ke0, 4e-3) and close(sim.get_potential_energy(), pe0, 8e-3)
+    sim.run(3)
+    ke3, pe3 = g[key + "/e3"]
+    tol = 1e-12 if mode == "float64" else 2e-6
+    assert close(sim.get_kinetic_energy(), ke3, max(tol, 1e-9)) and close(sim.get_potential_energy(), pe3, max(tol, 1e-9))
+    assert relerr(sim.positions, g[key + "/pos3"]) < (1e-12 if mode == "float64" else 1e-5)
+    assert relerr(sim.velocities, g[key + "/vel3"]) < (1e-10 if mode == "float64" else 1e-4)
+    names = {O.F16: "torch.float16", O.BF16: "torch.bfloat16", O.F32: "torch.float32", O.F64: "torch.float64"}
+    assert [names[c] for c in (sim.codes[0], sim.codes[1], sim.codes[3], sim.codes[2])] == list(g[key + "/dtypes3"])
