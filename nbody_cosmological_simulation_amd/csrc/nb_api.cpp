@@ -887,6 +887,10 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential)
     if (potential) {
         const int t = promote(s->logical[0], s->logical[2]);
         *potential = round_dt(t, round_dt(t, -c.G) * round_dt(t, host[1]));
+        // the reference multiplies by the triu mask before dividing by dist (simulation.py:189): the masked
+        // entries are 0 / dist = NaN where dist == 0, i.e. on the whole diagonal when the softening rounds to
+        // zero in the positions' dtype (softening 0; 1e-4 with float16 positions).  dist > 0 otherwise.
+        if (c.n > 0 && round_dt(s->logical[0], c.softening_sq) == 0.0) *potential = std::nan("");
     }
     return NB_OK;
 }

@@ -420,6 +420,10 @@ double nbo_potential_energy(int n, int d, int P, const double *pos, int M, const
         }
         total += part;
     }
+    /* the reference multiplies by the triu mask BEFORE dividing (simulation.py:189): masked entries are 0 / dist,
+     * which is NaN where dist == 0 -- on the whole diagonal when the softening rounds to zero in the positions'
+     * dtype (softening 0, or 1e-4 with float16 positions).  For a non-zero softening dist > 0 everywhere. */
+    if (n > 0 && j0 == 0 && scalar_as(P, eps2_py) == 0.0) return NAN;
     total = rnd(T, total);
     return rnd(T, scalar_as(T, -G) * total);
 }

@@ -23,6 +23,7 @@ What is captured:
   G5  tensor-level hooks: quantize_distance_squared / quantize_force / _grid_quantize*
       on random tensors.
   G6  initial-condition generators and diagnostics (galaxy.py / metrics.py), seeded.
+  G8  parameter extremes (softening 0 / 1e-4 ... 1.0, dt up to 2.0) through the stock class, incl. the NaN cases.
   G7  half-typed state (float16 / bfloat16 tensors) through the cast modes and FLOAT64: energies before
       and after the promotion, state after three steps.
 
@@ -443,7 +444,36 @@ def g7():
     np.savez_compressed(os.path.join(OUT, "g7_half_state.npz"), **out)
 
 
+def g8():
+    """Parameter extremes of crash_point_test.py:243,412 and falsification_tests.py:284-285 through the stock class:
+    softening 1e-4 ... 1.0 (below the grid clamp, below float16's smallest subnormal squared -> NaN upstream),
+    dt up to 2.0, softening 0 in FLOAT64 mode (0/0 on the diagonal)."""
+    out = {}
+    pos, vel, mass = disk_ics(150, 8)
+    out["pos"], out["vel"], out["mass"] = npy(pos), npy(vel), npy(mass)
+    cases = [("float32", 1e-4, 0.01), ("float32", 1e-4, 2.0), ("float32", 1.0, 0.01), ("float32", 1.0, 2.0),
+             ("float16", 1e-4, 0.01), ("float16", 0.05, 0.05), ("bfloat16", 1e-3, 0.02),
+             ("int4_sim", 1e-4, 0.05), ("int8_sim", 1.0, 0.5), ("custom", 1e-3, 0.01),
+             ("float64", 0.0, 0.01), ("float64", 1e-4, 2.0)]
+    names = []
+    for mode_name, eps, dt in cases:
+        mode = PrecisionMode(mode_name)
+        sim = ref_sim.GalaxySimulation(pos.clone(), vel.clone(), mass.clone(), precision_mode=mode, G=0.001, dt=dt,
+                                       softening=eps)
+        key = f"{mode_name}/eps{eps}/dt{dt}"
+        names.append(key)
+        out[key + "/acc0"] = npy(sim.accelerations).astype(np.float64)
+        out[key + "/e0"] = np.array([sim.get_kinetic_energy(), sim.get_potential_energy()])
+        for _ in range(5):
+            sim.step()
+        out[key + "/pos5"] = npy(sim.positions).astype(np.float64)
+        out[key + "/vel5"] = npy(sim.velocities).astype(np.float64)
+        out[key + "/e5"] = np.array([sim.get_kinetic_energy(), sim.get_potential_energy()])
+    out["cases"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "g8_extremes.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         globals()[w]()

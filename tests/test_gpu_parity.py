@@ -1084,3 +1084,17 @@ def test_half_typed_state_vs_reference_golden(nb, n, hname, mode):
     assert relerr(sim.velocities.double().numpy(), g[key + "/vel3"]) < (1e-10 if mode == "float64" else 1e-4)
     assert [str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.accelerations.dtype), str(sim.masses.dtype)] == \
         list(g[key + "/dtypes3"])
+
+
+@pytest.mark.parametrize("idx", range(12))
+def test_parameter_extremes_vs_reference_golden(nb, idx):
+    """g8: softening 0 / 1e-4 / 1.0, dt up to 2.0 through the stock class (crash_point_test.py, falsification_tests.py)
+    -- NaN patterns (FLOAT16 at softening 1e-4, FLOAT64 at softening 0 incl. the NaN potential), grid clamps, and
+    the violent dt = 2 runs against the reference's own numbers."""
+    from test_oracle_golden import _g8_check
+    g = load_golden("g8_extremes.npz")
+    key = str(g["cases"][idx])
+    _g8_check(lambda mode, eps, dt: nb.GalaxySimulation(T(g["pos"]), T(g["vel"]), T(g["mass"]),
+                                                        precision_mode=nb.PrecisionMode(mode), G=0.001, softening=eps,
+                                                        dt=dt),
+              key, g, key.startswith("float64"))

@@ -310,3 +310,47 @@ def test_g7_half_typed_state(n, hname, code, mode):
     assert relerr(sim.velocities, g[key + "/vel3"]) < (1e-10 if mode == "float64" else 1e-4)
     names = {O.F16: "torch.float16", O.BF16: "torch.bfloat16", O.F32: "torch.float32", O.F64: "torch.float64"}
     assert [names[c] for c in (sim.codes[0], sim.codes[1], sim.codes[3], sim.codes[2])] == list(g[key + "/dtypes3"])
+
+
+def _g8_check(get_sim, key, g, f64):
+    """Shared by the oracle (here) and the engine (tests/test_gpu_parity.py): one g8 case against the reference."""
+    mode, eps, dt = key.split("/")
+    eps, dt = float(eps[3:]), float(dt[2:])
+    sim = get_sim(mode, eps, dt)
+    wild = dt >= 1.0 and eps <= 1e-3          # 2-unit steps through 1e-4-softened encounters: rounding is amplified
+
+    def same(got, want, tol):
+        got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+        if not np.array_equal(np.isnan(got), np.isnan(want)):
+            return False
+        ok = ~np.isnan(want)
+        return ok.sum() == 0 or np.abs(got[ok] - want[ok]).max() <= tol * max(np.abs(want[ok]).max(), 1e-300)
+
+    acc = sim.accelerations
+    acc = acc.double().numpy() if hasattr(acc, "double") else acc
+    assert same(acc, g[key + "/acc0"], 1e-13 if f64 else 2e-6), key
+    # tick 0: the state is still fp32-typed in every mode (fp32 inputs), so the energies are fp32 sums
+    assert same([sim.get_kinetic_energy(), sim.get_potential_energy()], g[key + "/e0"], 2e-6), key
+    sim.run(5)
+    pos, vel = sim.positions, sim.velocities
+    pos = pos.double().numpy() if hasattr(pos, "double") else pos
+    vel = vel.double().numpy() if hasattr(vel, "double") else vel
+    tol = 5e-2 if (wild and not f64) else (1e-9 if f64 else 1e-5)
+    assert same(pos, g[key + "/pos5"], tol), key
+    assert same(vel, g[key + "/vel5"], tol * (1 if f64 or wild else 10)), key
+    # (the bf16 / softening 1e-3 run gains 45x its kinetic energy in five steps: a half-precision rounding flip of
+    # one close pair's r2 moves it by 1e-5)
+    e_tol = 5e-2 if wild and not f64 else (1e-9 if f64 else 1e-4)
+    assert same([sim.get_kinetic_energy()], [g[key + "/e5"][0]], e_tol), key
+    assert same([sim.get_potential_energy()], [g[key + "/e5"][1]], e_tol), key
+
+
+@pytest.mark.parametrize("idx", range(12))
+def test_g8_parameter_extremes(idx):
+    """crash_point_test.py / falsification_tests.py parameter ranges through the stock class: softening 0 (NaN
+    forces and NaN potential, like the reference's masked 0/0), 1e-4 (NaN in FLOAT16 mode, where it underflows),
+    1.0; dt up to 2.0; grid modes below their 0.01 clamp."""
+    g = load_golden("g8_extremes.npz")
+    key = str(g["cases"][idx])
+    _g8_check(lambda mode, eps, dt: O.OracleSim(g["pos"], g["vel"], g["mass"], mode, G=0.001, softening=eps, dt=dt),
+              key, g, key.startswith("float64"))
