@@ -24,6 +24,7 @@ What is captured:
       on random tensors.
   G6  initial-condition generators and diagnostics (galaxy.py / metrics.py), seeded.
   G8  parameter extremes (softening 0 / 1e-4 ... 1.0, dt up to 2.0) through the stock class, incl. the NaN cases.
+  G9  degenerate systems: N = 1, 2, 3, coincident particles, a massless particle (all seven modes).
   G7  half-typed state (float16 / bfloat16 tensors) through the cast modes and FLOAT64: energies before
       and after the promotion, state after three steps.
 
@@ -473,7 +474,40 @@ def g8():
     np.savez_compressed(os.path.join(OUT, "g8_extremes.npz"), **out)
 
 
+def g9():
+    """Degenerate systems through the stock class, all seven modes: N = 1, 2, 3, five coincident particles,
+    a massless particle.  Accelerations, energies, state after two steps."""
+    out = {}
+    gen = torch.Generator().manual_seed(9)
+    systems = {}
+    for n in (1, 2, 3):
+        systems[f"n{n}"] = ((torch.randn(n, 2, generator=gen) * 3).float(), (torch.randn(n, 2, generator=gen) * 0.1).float(),
+                            (0.5 + torch.rand(n, generator=gen)).float())
+    systems["coincident5"] = (torch.full((5, 2), 1.25), (torch.randn(5, 2, generator=gen) * 0.1).float(), torch.ones(5))
+    p = (torch.randn(6, 3, generator=gen) * 3).float()
+    m = torch.ones(6)
+    m[2] = 0.0
+    systems["massless_d3"] = (p, (torch.randn(6, 3, generator=gen) * 0.1).float(), m)
+    names = []
+    for sname, (pos, vel, mass) in systems.items():
+        out[f"{sname}/pos"], out[f"{sname}/vel"], out[f"{sname}/mass"] = npy(pos), npy(vel), npy(mass)
+        for mode in MODES:
+            sim = ref_sim.GalaxySimulation(pos.clone(), vel.clone(), mass.clone(), precision_mode=mode, G=0.001, dt=0.01,
+                                           softening=0.1)
+            key = f"{sname}/{mode.value}"
+            names.append(key)
+            out[key + "/acc0"] = npy(sim.accelerations).astype(np.float64)
+            out[key + "/e0"] = np.array([sim.get_kinetic_energy(), sim.get_potential_energy()])
+            sim.step()
+            sim.step()
+            out[key + "/pos2"] = npy(sim.positions).astype(np.float64)
+            out[key + "/vel2"] = npy(sim.velocities).astype(np.float64)
+            out[key + "/e2"] = np.array([sim.get_kinetic_energy(), sim.get_potential_energy()])
+    out["cases"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "g9_degenerate.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()

@@ -1098,3 +1098,12 @@ def test_parameter_extremes_vs_reference_golden(nb, idx):
                                                         precision_mode=nb.PrecisionMode(mode), G=0.001, softening=eps,
                                                         dt=dt),
               key, g, key.startswith("float64"))
+
+
+@pytest.mark.parametrize("idx", range(35))
+def test_degenerate_systems_vs_reference_golden(nb, idx):
+    """g9: N = 1, 2, 3, coincident particles, a massless particle (3-D), all seven modes against the reference."""
+    from test_oracle_golden import _g9_check
+    g = load_golden("g9_degenerate.npz")
+    _g9_check(lambda p, v, m, mode: nb.GalaxySimulation(T(p), T(v), T(m), precision_mode=nb.PrecisionMode(mode)),
+              str(g["cases"][idx]), g)

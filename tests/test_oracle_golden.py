@@ -354,3 +354,31 @@ def test_g8_parameter_extremes(idx):
     key = str(g["cases"][idx])
     _g8_check(lambda mode, eps, dt: O.OracleSim(g["pos"], g["vel"], g["mass"], mode, G=0.001, softening=eps, dt=dt),
               key, g, key.startswith("float64"))
+
+
+def _g9_check(get_sim, key, g):
+    sname, mode = key.split("/")
+    sim = get_sim(g[sname + "/pos"], g[sname + "/vel"], g[sname + "/mass"], mode)
+    f64 = mode == "float64"
+
+    def same(got, want, tol):
+        got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+        if got.shape != want.shape or not np.array_equal(np.isnan(got), np.isnan(want)):
+            return False
+        ok = ~np.isnan(want)
+        return ok.sum() == 0 or np.abs(got[ok] - want[ok]).max() <= tol * max(np.abs(want[ok]).max(), 1e-300)
+
+    tonp = lambda t: t.double().numpy() if hasattr(t, "double") else t
+    assert same(tonp(sim.accelerations), g[key + "/acc0"], 1e-13 if f64 else 2e-6), key
+    assert same([sim.get_kinetic_energy(), sim.get_potential_energy()], g[key + "/e0"], 2e-6), key
+    sim.run(2)
+    assert same(tonp(sim.positions), g[key + "/pos2"], 1e-13 if f64 else 1e-6), key
+    assert same(tonp(sim.velocities), g[key + "/vel2"], 1e-12 if f64 else 1e-6), key
+    assert same([sim.get_kinetic_energy(), sim.get_potential_energy()], g[key + "/e2"], 1e-12 if f64 else 2e-6), key
+
+
+@pytest.mark.parametrize("idx", range(35))
+def test_g9_degenerate_systems(idx):
+    """N = 1, 2, 3, five coincident particles, a massless particle in 3-D, every mode (reference run, g9)."""
+    g = load_golden("g9_degenerate.npz")
+    _g9_check(lambda p, v, m, mode: O.OracleSim(p, v, m, mode), str(g["cases"][idx]), g)
