@@ -25,6 +25,7 @@ What is captured:
   G6  initial-condition generators and diagnostics (galaxy.py / metrics.py), seeded.
   G8  parameter extremes (softening 0 / 1e-4 ... 1.0, dt up to 2.0) through the stock class, incl. the NaN cases.
   G9  degenerate systems: N = 1, 2, 3, coincident particles, a massless particle (all seven modes).
+  G10 tensor-level hooks on awkward inputs (0, negative, 1e30, inf, NaN, 2-3 levels, 1-D / 3-D / single element).
   G7  half-typed state (float16 / bfloat16 tensors) through the cast modes and FLOAT64: energies before
       and after the promotion, state after three steps.
 
@@ -507,7 +508,37 @@ def g9():
     np.savez_compressed(os.path.join(OUT, "g9_degenerate.npz"), **out)
 
 
+def g10():
+    """Tensor-level hooks on awkward inputs: zeros, negatives, huge values, inf, NaN, two or three levels, odd
+    shapes (1-D, 3-D, a single element), every mode."""
+    g = torch.Generator().manual_seed(10)
+    out = {}
+    base = (torch.rand(40, 40, generator=g) * 30.0 + 0.02).float()
+    tens = {}
+    t = base.clone(); t[0, 0] = 0.0; t[1, 1] = -4.0; t[2, 2] = 1e30; t[3, 3] = 1e-30
+    tens["zero_neg_huge"] = t
+    t = base.clone(); t[5, 6] = float("inf")
+    tens["inf"] = t
+    t = base.clone(); t[7, 8] = float("nan")
+    tens["nan"] = t
+    tens["vec1d"] = base[0].clone()
+    tens["cube3d"] = base[:27, :8].reshape(3, 9, 8).clone()
+    tens["single"] = torch.tensor([[2.5]])
+    names = []
+    for name, t in tens.items():
+        out[f"in/{name}"] = npy(t)
+        for mode in MODES:
+            out[f"{name}/qd2/{mode.value}"] = npy(ref_quant.quantize_distance_squared(t, mode))
+            out[f"{name}/qf/{mode.value}"] = npy(ref_quant.quantize_force(t - 15.0, mode))
+        for L in (2, 3, 7):
+            out[f"{name}/safe/L{L}"] = npy(ref_quant._grid_quantize_safe(t, L, min_val=0.01))
+            out[f"{name}/lin/L{L}"] = npy(ref_quant._grid_quantize(t - 15.0, L))
+        names.append(name)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "g10_hook_edges.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()

@@ -1107,3 +1107,14 @@ def test_degenerate_systems_vs_reference_golden(nb, idx):
     g = load_golden("g9_degenerate.npz")
     _g9_check(lambda p, v, m, mode: nb.GalaxySimulation(T(p), T(v), T(m), precision_mode=nb.PrecisionMode(mode)),
               str(g["cases"][idx]), g)
+
+
+@pytest.mark.parametrize("name", ["zero_neg_huge", "inf", "nan", "vec1d", "cube3d", "single"])
+def test_tensor_hook_edge_values_vs_reference_golden(nb, name):
+    """g10: the tensor-level hooks on zeros, negatives, 1e30, inf, NaN, 2-3 levels and odd shapes."""
+    from test_oracle_golden import _g10_check
+    g = load_golden("g10_hook_edges.npz")
+    _g10_check((lambda t, mode: nb.quantize_distance_squared(T(t), nb.PrecisionMode(mode)).numpy(),
+                lambda t, mode: nb.quantize_force(T(t), nb.PrecisionMode(mode)).numpy(),
+                lambda t, L, mv: nb._grid_quantize_safe(T(t), L, min_val=mv).numpy(),
+                lambda t, L: nb._grid_quantize(T(t), L).numpy()), g, name)

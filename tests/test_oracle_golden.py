@@ -382,3 +382,35 @@ def test_g9_degenerate_systems(idx):
     """N = 1, 2, 3, five coincident particles, a massless particle in 3-D, every mode (reference run, g9)."""
     g = load_golden("g9_degenerate.npz")
     _g9_check(lambda p, v, m, mode: O.OracleSim(p, v, m, mode), str(g["cases"][idx]), g)
+
+
+def _g10_check(fns, g, name):
+    """fns: (quantize_distance_squared, quantize_force, grid_quantize_safe, grid_quantize) taking numpy arrays."""
+    qd2, qf, safe, lin = fns
+    t = g["in/" + name]
+
+    def same(got, want, tol=1e-6):
+        got, want = np.asarray(got), np.asarray(want)
+        assert got.shape == want.shape and got.dtype == want.dtype, (name, got.shape, want.shape, got.dtype, want.dtype)
+        a, b = got.astype(np.float64), want.astype(np.float64)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), name
+        inf = np.isinf(b)
+        assert np.array_equal(a[inf], b[inf]), name
+        ok = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), ok), name
+        if ok.any():
+            assert np.abs(a[ok] - b[ok]).max() <= tol * max(np.abs(b[ok]).max(), 1e-300), name
+
+    for mode in MODES:
+        same(qd2(t, mode), g[f"{name}/qd2/{mode}"])
+        same(qf(t - np.float32(15.0), mode), g[f"{name}/qf/{mode}"])
+    for L in (2, 3, 7):
+        same(safe(t, L, 0.01), g[f"{name}/safe/L{L}"])
+        same(lin(t - np.float32(15.0), L), g[f"{name}/lin/L{L}"])
+
+
+@pytest.mark.parametrize("name", ["zero_neg_huge", "inf", "nan", "vec1d", "cube3d", "single"])
+def test_g10_hook_edge_values(name):
+    """Tensor-level hooks on zeros, negatives, 1e30, inf, NaN, 2-3 levels, 1-D / 3-D / one-element tensors (g10)."""
+    g = load_golden("g10_hook_edges.npz")
+    _g10_check((O.quantize_distance_squared, O.quantize_force, O.grid_quantize_safe, O.grid_quantize), g, name)
