@@ -40,13 +40,17 @@ def compute_rotation_curve(positions: torch.Tensor, velocities: torch.Tensor, nu
     v_tan = torch.abs(positions[:, 0] * velocities[:, 1] - positions[:, 1] * velocities[:, 0]) / radii.clamp(min=0.1)
     edges = torch.linspace(0, max_radius, num_bins + 1, device=positions.device)
     centres = (edges[:-1] + edges[1:]) / 2
-    means, counts = [], []
-    for i in range(num_bins):
-        mask = (radii >= edges[i]) & (radii < edges[i + 1])
-        cnt = int(mask.sum().item())
-        counts.append(cnt)
-        means.append(v_tan[mask].mean().item() if cnt > 0 else float("nan"))
-    return {"radii": centres.cpu().numpy(), "velocities": np.array(means), "num_stars_per_bin": counts}
+    # membership of bin i is edge_i <= r < edge_{i+1} exactly as upstream's masks (r == max_radius falls out of
+    # the last bin); all bins in one pass and one device-to-host transfer instead of two per bin.  Sums go
+    # through a one-hot matrix product: deterministic (no atomics), accumulated in fp64.
+    member = (radii.unsqueeze(1) >= edges[:-1].unsqueeze(0)) & (radii.unsqueeze(1) < edges[1:].unsqueeze(0))
+    onehot = member.to(torch.float64)
+    counts_t = onehot.sum(dim=0)
+    sums = onehot.t() @ v_tan.to(torch.float64)
+    means_t = (sums / counts_t).to(v_tan.dtype)           # 0 / 0 = NaN for empty bins, like upstream
+    stacked = torch.stack([means_t.to(torch.float64), counts_t]).cpu().numpy()
+    return {"radii": centres.cpu().numpy(), "velocities": stacked[0].astype(np.float64),
+            "num_stars_per_bin": [int(c) for c in stacked[1]]}
 
 
 def compute_galaxy_radius(positions: torch.Tensor, percentile: float = 90) -> float:
