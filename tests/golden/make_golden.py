@@ -26,6 +26,7 @@ What is captured:
   G8  parameter extremes (softening 0 / 1e-4 ... 1.0, dt up to 2.0) through the stock class, incl. the NaN cases.
   G9  degenerate systems: N = 1, 2, 3, coincident particles, a massless particle (all seven modes).
   G10 tensor-level hooks on awkward inputs (0, negative, 1e30, inf, NaN, 2-3 levels, 1-D / 3-D / single element).
+  G11 galaxy generators with non-default parameters.
   G7  half-typed state (float16 / bfloat16 tensors) through the cast modes and FLOAT64: energies before
       and after the promotion, state after three steps.
 
@@ -538,7 +539,26 @@ def g10():
     np.savez_compressed(os.path.join(OUT, "g10_hook_edges.npz"), **out)
 
 
+def g11():
+    """Galaxy generators with non-default parameters (radius, core fraction, halo radius, dark-matter ratio,
+    tiny and odd star counts)."""
+    out = {}
+    cases = [("disk_r5_c0.6", ref_galaxy.create_disk_galaxy, dict(num_stars=777, galaxy_radius=5.0, core_mass_fraction=0.6)),
+             ("disk_r40_c0", ref_galaxy.create_disk_galaxy, dict(num_stars=1234, galaxy_radius=40.0, core_mass_fraction=0.0)),
+             ("disk_n3", ref_galaxy.create_disk_galaxy, dict(num_stars=3)),
+             ("test_n17", ref_galaxy.create_test_galaxy, dict(num_stars=17)),
+             ("halo_r8_h50_dm20", ref_galaxy.create_galaxy_with_halo,
+              dict(num_stars=900, galaxy_radius=8.0, halo_radius=50.0, dm_mass_ratio=20.0)),
+             ("halo_dm0", ref_galaxy.create_galaxy_with_halo, dict(num_stars=500, dm_mass_ratio=0.0))]
+    for name, fn, kw in cases:
+        torch.manual_seed(11)
+        p, v, m = fn(device=torch.device("cpu"), **kw)
+        out[f"{name}/pos"], out[f"{name}/vel"], out[f"{name}/mass"] = npy(p), npy(v), npy(m)
+        out[f"{name}/dtypes"] = np.array([str(p.dtype), str(v.dtype), str(m.dtype)])
+    np.savez_compressed(os.path.join(OUT, "g11_generators.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()
