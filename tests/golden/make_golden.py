@@ -27,6 +27,7 @@ What is captured:
   G9  degenerate systems: N = 1, 2, 3, coincident particles, a massless particle (all seven modes).
   G10 tensor-level hooks on awkward inputs (0, negative, 1e30, inf, NaN, 2-3 levels, 1-D / 3-D / single element).
   G11 galaxy generators with non-default parameters.
+  G12 main.py's metric flow (collect_metrics in a run() callback, compare_rotation_curves).
   G7  half-typed state (float16 / bfloat16 tensors) through the cast modes and FLOAT64: energies before
       and after the promotion, state after three steps.
 
@@ -558,7 +559,34 @@ def g11():
     np.savez_compressed(os.path.join(OUT, "g11_generators.npz"), **out)
 
 
+def g12():
+    """main.py's metric flow: collect_metrics every 10 ticks over 30 ticks (float64 and int4), the rotation-curve
+    comparison of the two final states, and the numbers behind the text summary."""
+    out = {}
+    pos, vel, mass = disk_ics(300, 12)
+    out["pos"], out["vel"], out["mass"] = npy(pos), npy(vel), npy(mass)
+    finals = {}
+    for mode in (PrecisionMode.FLOAT64, PrecisionMode.INT4_SIM):
+        sim = ref_sim.GalaxySimulation(pos.clone(), vel.clone(), mass.clone(), precision_mode=mode, G=0.001, dt=0.01,
+                                       softening=0.1)
+        m = ref_metrics.SimulationMetrics()
+        ref_metrics.collect_metrics(sim, 0, m)
+        sim.run(30, callback=lambda s, t: ref_metrics.collect_metrics(s, t, m), callback_interval=10)
+        k = mode.value
+        out[f"{k}/ticks"] = np.array(m.ticks)
+        for f in ("total_energy", "kinetic_energy", "potential_energy", "galaxy_radius_90", "bound_fraction",
+                  "velocity_dispersion"):
+            out[f"{k}/{f}"] = np.array(getattr(m, f), dtype=np.float64)
+        out[f"{k}/rc_v"] = np.array([rc["velocities"] for rc in m.rotation_curves], dtype=np.float64)
+        out[f"{k}/rc_n"] = np.array([rc["num_stars_per_bin"] for rc in m.rotation_curves])
+        finals[k] = m.rotation_curves[-1]
+    cmp_ = ref_metrics.compare_rotation_curves(finals["float64"], finals["int4_sim"])
+    for key, val in cmp_.items():
+        out[f"compare/{key}"] = np.float64(val)
+    np.savez_compressed(os.path.join(OUT, "g12_metric_flow.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()
