@@ -214,7 +214,9 @@ int build_sym_plan(nb_sim *s)
     // And at the very small end (fp64, 2-D) tiles of 64 (R = 1: one 64-step sweep of single pairs per wave, ~4 us)
     // beat the one-sided kernel: 12.1 vs 16.6 us per step at N = 1024, 13.1 vs 18.3 at 2560, 18.1 vs 18.7 at 3000.
     const bool tiny = s->is_f64 && c.dim == 2 && c.n <= 2816;
-    const int sym_from = s->is_f64 ? 5120 : 1024;     // fp32 family: R = 2 already wins at N = 1024 (14.2 vs 15.4 us; INT4 51 vs 62)
+    // fp32 family: R = 2 already wins at N = 1024 (14.2 vs 15.4 us; INT4 51 vs 62).  3-D crosses over later
+    // (fp64: 8192 56.9 one-sided vs 60.5, 12288 131 vs 92.6; fp32: 3000 19.8 vs 20.0, 8192 52.3 vs 36.0).
+    const int sym_from = c.dim == 3 ? (s->is_f64 ? 10240 : 4096) : (s->is_f64 ? 5120 : 1024);
     int want = (tiny || c.n >= sym_from) ? 1 : 0;
     if (const char *e = getenv("NB_SYM")) want = atoi(e);
     // comm-less shards (NB_FLAG_NO_COMM) use the one-sided kernel unless NB_SYM=2 asks for the symmetric

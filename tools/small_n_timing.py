@@ -6,6 +6,9 @@ ns = [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384]
 mode = nb.get_mode_from_string(__import__("os").environ.get("MODE", "float64"))
 for n in ns:
     pos, vel, mass = galaxy.create_disk_galaxy(n, seed=42, device="cpu")
+    if __import__("os").environ.get("DIM") == "3":          # 3-D cloud (reality_glitch_tests.py runs (N,3) tensors)
+        torch.manual_seed(0)
+        pos, vel = torch.randn(n, 3) * 5, torch.randn(n, 3) * 0.05
     sim = nb.GalaxySimulation(pos.cuda(), vel.cuda(), mass.cuda(), precision_mode=mode)
     t = time.perf_counter()
     while time.perf_counter() - t < 0.1:          # ~100 ms of steps: past the clock ramp
