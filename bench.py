@@ -7,21 +7,28 @@
 
 A "step" is one GalaxySimulation.step() (kick-drift-force-kick) over the whole galaxy:
 BASELINE.json config 2 -- N=65 536 synthetic disk galaxy, fp32 initial conditions, FLOAT64
-mode, G=1e-3, softening=0.1, dt=0.01.  With N GPUs the SAME galaxy is stepped with the
-source loop block-partitioned over the ranks and one RCCL all-reduce of the force vectors
-per step (strong scaling).  The state is resident in HBM before the timed region starts;
-the K timed steps are ONE native call (nb_step) bracketed by barrier + device sync.
+mode, G=1e-3, softening=0.1, dt=0.01.  With N GPUs the SAME galaxy is stepped with the pair
+work partitioned over the ranks (snake-dealt target super-rows of the pair-symmetric kernel)
+and one RCCL all-reduce of the force vectors per step (strong scaling).  The state is resident
+in HBM before the timed region starts; the K timed steps are ONE native call (nb_step)
+bracketed by barrier + device sync.  `python bench.py --gpus N` without RANK in the
+environment starts the N ranks itself (a child `python -m torch.distributed.run`, before this
+process touches torch or HIP) and relays rank 0's JSON line.
 
 Rank 0 prints one JSON line (contract in the task description) with two extra objects:
-  roofline      dominant kernel (force_f64_kernel) algorithmic fp64 flop (14 per ordered pair,
-                SURVEY.md section 8d) / its HIP-event duration measured inside this run, against
-                the fp64 vector peak of MI355X.
+  roofline      dominant kernel (force_sym_kernel<double,...>; the line names the one that ran)
+                algorithmic fp64 flop (14 per ordered pair) / its HIP-event
+                duration measured inside this run, against the fp64 vector peak of MI355X.
   cpu_baseline  the CPU oracle (oracle/, "port" of the reference's algorithm, OpenMP over all
-                host cores) timed on a bounded sample of the same workload (rank 0, N=1 only).
+                host cores) timed on a bounded sample of the same workload (rank 0, N=1 only),
+                the energy drift of the GPU run against the oracle's over those same steps, and
+                the reference's own materialised-tensor formulation timed per SURVEY.md 8(d).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -44,12 +51,36 @@ def parse():
                          "own parser takes --n for an abbreviation of --nnodes")
     ap.add_argument("--mode", default="float64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample length")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample length")
+    ap.add_argument("--ref-sizes", default="1024,4096,8192",
+                    help="sizes at which the reference's materialised torch formulation is timed (SURVEY.md 8d); '' = skip")
     return ap.parse_args()
 
 
-def cpu_baseline(pos, vel, mass, target_s):
-    """Oracle (C port of the reference algorithm, all host cores) on a bounded sample."""
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process (nothing
+    in this process has touched torch or HIP yet, and nothing will), relay its output, return its exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines:
+            print(ln, file=sys.stderr)
+    if json_lines:
+        print(json_lines[-1], flush=True)          # rank 0's bench line
+    return proc.returncode
+
+
+def cpu_baseline(pos, vel, mass, target_s, ref_sizes, gpu_drift):
+    """Oracle (C port of the reference algorithm, all host cores) on a bounded sample of the bench workload;
+    `gpu_drift(steps)` returns the GPU engine's relative energy drift over the same steps from the same ICs."""
     import numpy as np
     from oracle import oracle as O
     p = np.ascontiguousarray(pos.double().numpy())
@@ -62,53 +93,70 @@ def cpu_baseline(pos, vel, mass, target_s):
     lib.nbo_accelerations_f64_fast(n, d, O._dp(p), O._dp(m), 0.001, 0.1 ** 2, 0, n, O._dp(acc))
     t_first = time.perf_counter() - t0
     steps = max(1, min(50, int(target_s / max(t_first, 1e-3))))
+
+    def energy():
+        ke = lib.nbo_kinetic_energy(n, d, O.F64, O._dp(v), O.F64, O._dp(m))
+        return ke + O.potential_energy_f64_fast(p, m)
+
+    e0 = energy()
     t0 = time.perf_counter()
     lib.nbo_step_f64_fast(n, d, O._dp(p), O._dp(v), O._dp(m), O._dp(acc), 0.001, 0.1 ** 2, 0.01, steps)
     dt = time.perf_counter() - t0
-    # the reference's own (materialised N x N x D torch) formulation cannot reach N = 65536; time it at
-    # the largest comfortable size on the same cores for context (SURVEY.md section 8d CPU baseline (ii))
-    ref_form = None
+    drift_oracle = (energy() - e0) / abs(e0)
+    drift_gpu = gpu_drift(steps)
+    # The reference's own (materialised N x N x D torch) formulation cannot reach N = 65536; SURVEY.md section 8(d)
+    # prescribes timing it at N in {1024, 4096, 8192}, fp64 and fp32, omega_point_test.py:305-319 idiom
+    # (10 warm-up steps, perf_counter, >= 10 steps), thread count stated.
+    ref_form = []
     try:
         import torch
         from oracle import torch_materialised as TM
-        nr = 4096
-        best = None
-        for threads in (None, 16):          # torch's default thread count (what a user gets), and 16
-            rt, used = TM.time_steps(pos[:nr].clone(), vel[:nr].clone(), mass[:nr].clone(), steps=3, warmup=1,
-                                     threads=threads)
-            row = {"value": nr * 3 / rt, "threads": used, "pair_interactions_per_s": float(nr) * nr * 3 / rt}
-            if best is None or row["value"] > best["value"]:
-                best = row
-        ref_form = dict(best, unit="particle-steps/s", n=nr,
-                        what="reference formulation (materialised torch broadcasts, simulation.py:74-143) restated "
-                             "in oracle/torch_materialised.py, FLOAT64 mode, 3 steps, best of torch-default / 16 threads")
+        threads = torch.get_num_threads()
+        for nr in ref_sizes:
+            for mode in ("float64", "float32"):
+                rt, used = TM.time_steps(pos[:nr].clone(), vel[:nr].clone(), mass[:nr].clone(), steps=10, warmup=10,
+                                         mode=mode, threads=threads)
+                ref_form.append({"n": nr, "mode": mode, "ms_per_step": rt / 10 * 1e3, "particle_steps_per_s": nr * 10 / rt,
+                                 "pair_interactions_per_s": float(nr) * nr * 10 / rt, "threads": used})
     except Exception as exc:            # never let the context measurement break the bench line
-        ref_form = {"error": repr(exc)}
+        ref_form.append({"error": repr(exc)})
     return {
-        "reference_formulation_torch_cpu": ref_form,
         "value": n * steps / dt, "unit": "particle-steps/s", "cores": O.num_threads(), "kind": "port",
         "sample": f"N={n} fp64 disk galaxy, {steps} leapfrog steps of the oracle's OpenMP fast path "
                   f"({dt:.1f} s; the reference's own PyTorch formulation cannot run at this N)",
         "pair_interactions_per_s": float(n) * n * steps / dt,
+        "energy_drift_rel_oracle": drift_oracle, "energy_drift_rel_gpu": drift_gpu,
+        "energy_drift_vs_oracle": abs(drift_gpu - drift_oracle), "energy_drift_steps": steps,
+        "energy_drift_note": "same fp64 initial conditions on both sides (fp32-representable values), "
+                             "(E_k - E_0)/|E_0| after the k steps the oracle sample runs",
+        "reference_formulation_torch_cpu": {
+            "what": "the reference's formulation (materialised torch broadcasts, simulation.py:74-143) restated in "
+                    "oracle/torch_materialised.py; 10 warm-up + 10 timed steps per row (omega_point_test.py:305-319 idiom)",
+            "rows": ref_form},
     }
 
 
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary (collected
-    in separate --pmc passes as the MI355X guide prescribes), or None when not profiled yet."""
+    """HBM bytes per launch of `kernel_name` from the COMMITTED rocprofv3 PMC summary (collected in separate
+    --pmc passes as the MI355X guide prescribes) with its provenance, or (None, why) when not profiled."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         summary = json.load(open(path))
     except OSError:
-        return None
+        return None, "no profiles/pmc_latest.json"
+    meta = summary.get("_meta", {})
     for name, counters in summary.items():
-        if name.startswith(kernel_name) and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
-            return (2.0 * counters["FETCH_SIZE"]["avg"] + counters["WRITE_SIZE"]["avg"]) * 1024.0
-    return None
+        if name.startswith(kernel_name) and isinstance(counters, dict) and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+            src = {"file": "profiles/pmc_latest.json (committed; NOT measured in this run)", "kernel": name}
+            src.update(meta)
+            return (2.0 * counters["FETCH_SIZE"]["avg"] + counters["WRITE_SIZE"]["avg"]) * 1024.0, src
+    return None, "kernel not in profiles/pmc_latest.json"
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(args)          # before anything imports torch or touches HIP
     import torch
     import torch.distributed as dist
 
@@ -176,6 +224,9 @@ def main():
             avg_ms = elapsed / args.steps * 1e3
             timing = "events off: kernel time bounded above by the whole step (includes O(N) kernels and the all-reduce)"
         achieved = FLOP_PER_PAIR_2D * pairs_per_launch / (avg_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(kernel_name)
+        traffic_valid = isinstance(traffic_src, dict) and traffic_src.get("n", n) == n and \
+            traffic_src.get("mode", mode.value) == mode.value and traffic_src.get("n_gpus", 1) == world
         out = {
             "metric": f"particle-steps/sec (N={n} {'fp64' if is64 else args.mode} direct-sum leapfrog)",
             "value": n * args.steps / elapsed,
@@ -189,9 +240,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"N={n} exponential-disk galaxy (seed 42), fp32 ICs, {mode.value} mode, "
                                    f"G=1e-3 eps=0.1 dt=0.01, KDK leapfrog, all-pairs direct sum",
-                       "parallelism": f"j-block x{world} + RCCL all-reduce" if world > 1 else "single GPU"},
+                       "parallelism": runtime.partition_label(world)},
             "pair_interactions_per_s": float(n) * n * args.steps / elapsed,
-            "energy_drift_rel": (e1 - e0) / abs(e0),
+            "energy_drift_rel_timed_region": (e1 - e0) / abs(e0),
+            "energy_drift_note": "raw drift over the timed steps (after warm-up), for the record only; the metric's "
+                                 "rel-err against the oracle is cpu_baseline.energy_drift_vs_oracle",
             "roofline": {
                 "bound": "mfma",
                 "bound_note": "compute-bound: priced against the dense fp64 (fp32 modes: fp32) MFMA peak, which on MI355X "
@@ -201,20 +254,33 @@ def main():
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "avg_launch_ms": avg_ms, "launches": launches, "timing": timing,
                 "flop_per_launch": FLOP_PER_PAIR_2D * pairs_per_launch,
-                "traffic": pmc_traffic(kernel_name),
+                "traffic": traffic if traffic_valid else None,
+                "traffic_source": traffic_src,
                 "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes committed under profiles/ "
-                                "(2*FETCH_SIZE + WRITE_SIZE, gfx950 correction); dominated by the slab writes "
-                                "that make the sums order-deterministic, DESIGN.md section 2",
+                                "(2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), reported only when that profile's "
+                                "N / mode / GPU count match this run; dominated by the slab writes that make the "
+                                "sums order-deterministic, DESIGN.md section 2",
             },
         }
         if world == 1 and not args.no_cpu_baseline and is64:
-            out["cpu_baseline"] = cpu_baseline(pos, vel, mass, args.cpu_seconds)
+            def gpu_drift(k):
+                s2 = nb.GalaxySimulation(pos.double().to(dev), vel.double().to(dev), mass.double().to(dev),
+                                         precision_mode=mode, G=0.001, softening=0.1, dt=0.01, device=dev)
+                ea = s2.get_total_energy()
+                s2.run(k)
+                eb = s2.get_total_energy()
+                s2.close()
+                return (eb - ea) / abs(ea)
+            sizes = [int(v) for v in args.ref_sizes.split(",") if v.strip()]
+            out["cpu_baseline"] = cpu_baseline(pos, vel, mass, args.cpu_seconds, sizes, gpu_drift)
         print(json.dumps(out), flush=True)
-    sim.close()                       # communicator down on every rank before the process group goes
+    sim.close()
+    runtime.shutdown()                # the process communicator: collective, every rank, before the process group goes
     if launched:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 1
+#define NB_ABI_VERSION 2
 
 typedef enum nb_status {
     NB_OK = 0,
@@ -60,8 +60,8 @@ typedef struct nb_config {
     double  softening_sq;  /* softening**2 evaluated in Python double (simulation.py:59)    */
     double  dt;            /* time step                                                     */
     int32_t device;        /* HIP device ordinal                                            */
-    int32_t rank;          /* j-block shard index   (0 for a single GPU)                    */
-    int32_t nranks;        /* number of shards      (1 for a single GPU)                    */
+    int32_t rank;          /* shard index of this process (0 for a single GPU)              */
+    int32_t nranks;        /* number of shards = GPUs  (1 for a single GPU)                 */
     int32_t flags;         /* NB_FLAG_*                                                     */
 } nb_config;
 
@@ -158,10 +158,34 @@ int nb_grid_quantize_safe(int device, const void *in, void *out, int64_t count, 
 
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------------------------------- */
 
-/* Rank 0 obtains an id (ncclGetUniqueId) and ships the bytes to the other ranks by any
- * means (torch.distributed store / gloo broadcast); every rank then calls nb_comm_init. */
+/* Partition: every rank holds the full O(N) state.  The pair work is split by
+ * TARGET super-rows of the pair-symmetric kernel (snake-dealt, equal pair counts) -- or, on the one-sided
+ * kernels, by contiguous SOURCE blocks [rank*N/P, (rank+1)*N/P) -- each rank produces partial accelerations
+ * for all particles, and one RCCL all-reduce (sum) of the (n, dim) force vectors per step completes them
+ * (issued in 1..4 prefix slices that overlap the remaining pair work when a step is long enough).
+ *
+ * ONE communicator per process, shared by every handle of the process:
+ *   rank 0 obtains an id (ncclGetUniqueId) and ships the bytes to the other ranks by any means
+ *   (torch.distributed store / gloo broadcast); every rank then calls nb_comm_init on its first handle
+ *   (collective).  Later handles attach with nb_comm_init(h, NULL, 0) -- no communication.
+ *   nb_destroy() never touches the communicator; nb_comm_shutdown() destroys it and is collective:
+ *   every rank calls it once, after its last step and before the transport that carried the id goes away. */
 int nb_comm_unique_id(void *id_out, int32_t *id_bytes /* in: capacity, out: size */);
-int nb_comm_init(nb_sim *s, const void *id, int32_t id_bytes);
+int nb_comm_init(nb_sim *s, const void *id /* NULL: attach the existing process communicator */, int32_t id_bytes);
+int nb_comm_ready(void);      /* ranks of the process communicator, 0 when there is none */
+int nb_comm_shutdown(void);
+
+/* The work plan of the pair-symmetric kernels for one rank, computed WITHOUT a device (pure host code; what
+ * nb_set_state uploads).  For tests of the partition: the union over ranks must cover every tile pair once.
+ * info[0..11] = enabled, targets per lane R, tile size, padded tiles, padded particles, work items, row slots,
+ * column-slab entries, source tiles per item, pipeline chunks, column-slab MiB, row-slab MiB.
+ * work: items x 8 int32 {tile_i, jt_begin, jt_end, slot, slot_stride, col_ord, s_begin, s_count};
+ * row_slot0 / row_nslots / col_upto: one int32 per padded tile; chunk_work / chunk_tile: chunks + 1 offsets
+ * (work-item ranges / tile boundaries; chunk_tile is the same on every rank).  Any output may be NULL.
+ * multi != 0: a communicator will sum the partial forces (enables pipeline chunks); cus: compute units (256). */
+int nb_plan_debug(const nb_config *cfg, int32_t is_f64, int32_t multi, int32_t cus, int32_t info[16], int32_t *work,
+                  int64_t work_capacity, int32_t *row_slot0, int32_t *row_nslots, int32_t *col_upto,
+                  int32_t *chunk_work, int32_t *chunk_tile);
 
 /* ---- measurement --------------------------------------------------------------------- */
 

@@ -13,10 +13,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "nb_internal.h"
+#include "nb_plan.h"
 
 namespace {
 
@@ -110,6 +112,17 @@ int load_rccl()
                         g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?");                 \
     } while (0)
 
+// One RCCL communicator per PROCESS (= per GPU), shared by every simulation handle of the process: a
+// precision sweep builds seven simulations, not seven communicators.  Handles borrow it; only the explicit,
+// collective nb_comm_shutdown() destroys it -- never nb_destroy(), which Python may run from a garbage
+// collector at a different moment on every rank.
+struct ProcComm {
+    ncclComm_t comm = nullptr;
+    int nranks = 0, rank = 0, device = -1;
+};
+ProcComm g_pc;
+std::mutex g_pc_mu;
+
 constexpr int PROF_RING = 256;
 
 }  // namespace
@@ -135,15 +148,21 @@ struct nb_sim {
     double mass_value = 0.0;
     const char *last_kernel = "none";
     ForceGeom geom{};
-    // pair-symmetric fp64 path (nb_force_sym.hip)
+    // pair-symmetric path (nb_force_sym.hip): device mirror of the host plan (nb_plan.h)
     struct SymPlan {
         bool enabled = false;
         int r = 2, tile_b = 128, tiles = 0, np = 0, nwork = 0, nslots = 0;
         SymWork *work = nullptr;
         int *row_slot0 = nullptr, *row_nslots = nullptr, *col_upto = nullptr;
         void *packed = nullptr, *colslab = nullptr;   // storage type of the state (fp32 or fp64)
+        void *packed_alt = nullptr;                   // second packed buffer of the chunked multi-GPU step
         double *rowslab = nullptr;
+        std::vector<int> chunk_work, chunk_tile;      // pipeline chunks (host side, see nb_plan.h)
     } sym;
+    NbKnobs knobs;                       // environment knobs, read once in nb_create
+    // chunked multi-GPU step: second force stream, collective stream, events
+    hipStream_t fstream2 = nullptr, cstream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr, ev_force[4] = {nullptr, nullptr, nullptr, nullptr};
     ncclComm_t comm = nullptr;
     // profiling
     hipEvent_t ev_start[PROF_RING], ev_stop[PROF_RING];
@@ -158,6 +177,12 @@ namespace {
 int64_t nd(const nb_sim *s) { return (int64_t)s->cfg.n * s->cfg.dim; }
 
 bool grid_mode(int mode) { return mode >= NB_INT8_SIM; }
+// collectives run whenever a communicator is attached (a 1-rank communicator exercises the same RCCL calls on
+// a single GPU) and must exist when the pair work is really sharded
+bool comm_active(const nb_sim *s)
+{
+    return (s->cfg.nranks > 1 && !(s->cfg.flags & NB_FLAG_NO_COMM)) || s->comm != nullptr;
+}
 int mode_levels(const nb_config &c)
 {
     if (c.mode == NB_INT8_SIM) return 256;
@@ -181,10 +206,8 @@ void compute_geometry(nb_sim *s)
     // throughput-bound: R = 1 doubles the workgroups (N = 1024: 27.8 -> 17.6 us per step, N = 4096:
     // 32.5 -> 22.6 us)
     g.r = (n <= 8192) ? 1 : 2;
-    if (const char *e = getenv("NB_R")) {           // tuning knob: targets per thread (1, 2 or 4)
-        const int r = atoi(e);
-        if (r == 1 || r == 2 || r == 4) g.r = r;
-    }
+    if (s->knobs.r_onesided == 1 || s->knobs.r_onesided == 2 || s->knobs.r_onesided == 4)   // NB_R tuning knob
+        g.r = s->knobs.r_onesided;
     const int njr = std::max(g.j_end - g.j_begin, 1);
     const int itiles = (n + NB_BLOCK * g.r - 1) / (NB_BLOCK * g.r);
     const int max_chunks = (njr + NB_TJ - 1) / NB_TJ;
@@ -197,138 +220,38 @@ void compute_geometry(nb_sim *s)
     s->geom = g;
 }
 
-// Work list of the pair-symmetric kernel.  Rows (target tiles) are dealt to the ranks in a snake
-// pattern so every rank owns the same number of tile pairs to within one row; each owned row is
-// cut into chunks of `cl` source tiles = one workgroup each, longest chunks first.
+// Work list of the pair-symmetric kernel: planned on the host (nb_plan.cpp, device-free and testable on its
+// own through nb_plan_debug), mirrored here into device buffers.
 int build_sym_plan(nb_sim *s)
 {
     auto &sp = s->sym;
     sp.enabled = false;
     const nb_config &c = s->cfg;
-    // Small systems: the pair-symmetric kernel has too few work items to fill the chip (one 64-step sweep per
-    // wave is its floor: ~50 us per step with tiles of 256 at any N <= 8192) and the one-sided LDS kernel wins.
-    // Between the two regimes a finer tiling (R = 2: tiles of 128, four times the work items, sweeps a quarter
-    // as long) fills the chip earlier: measured fp64 us per step, one-sided / R = 2 / R = 4: N = 6144 38.9 / 30.8 /
-    // 51.5, 8192 47.4 / 44.5 / 52.1, 12288 113 / 66.5 / 81.0, 16384 149 / 107 / 118, 20480 - / 154 / 152, 32768 - /
-    // 366 / 310; fp32: N = 4096 18.6 / 16.1 / 37.0, 8192 40.2 / 26.4 / 38.3, 16384 118 / 61.4 / 70.8, 24576 269 / 118 / 105.
-    // And at the very small end (fp64, 2-D) tiles of 64 (R = 1: one 64-step sweep of single pairs per wave, ~4 us)
-    // beat the one-sided kernel: 12.1 vs 16.6 us per step at N = 1024, 13.1 vs 18.3 at 2560, 18.1 vs 18.7 at 3000.
-    const bool tiny = s->is_f64 && c.dim == 2 && c.n <= 2816;
-    // fp32 family: R = 2 already wins at N = 1024 (14.2 vs 15.4 us; INT4 51 vs 62).  3-D crosses over later
-    // (fp64: 8192 56.9 one-sided vs 60.5, 12288 131 vs 92.6; fp32: 3000 19.8 vs 20.0, 8192 52.3 vs 36.0).
-    const int sym_from = c.dim == 3 ? (s->is_f64 ? 10240 : 4096) : (s->is_f64 ? 5120 : 1024);
-    int want = (tiny || c.n >= sym_from) ? 1 : 0;
-    if (const char *e = getenv("NB_SYM")) want = atoi(e);
-    // comm-less shards (NB_FLAG_NO_COMM) use the one-sided kernel unless NB_SYM=2 asks for the symmetric
-    // plan of their rank (tests: the partial sums of all ranks' plans must add up to the full result)
-    if (!want || ((c.flags & NB_FLAG_NO_COMM) && want < 2)) return NB_OK;
-    if (s->is_f64 && c.mode != NB_FLOAT64) return NB_OK;    // fp64 state under a cast mode: one-sided kernel
-    // targets per lane.  Measured on MI355X, N=65536, D=2: R=1 3.39 ms, R=2 1.87 ms, R=4 1.47 ms.  D=3 also keeps
-    // four targets per lane and sweeps the source tile in two halves of two slots (sym_rj, nb_force_sym.hip)
-    sp.r = tiny ? 1 : (c.n < 20480) ? 2 : 4;
-    if (const char *e = getenv("NB_SYM_R")) {
-        const int r = atoi(e);
-        if ((r == 1 && s->is_f64 && c.dim == 2) || r == 2 || r == 4) sp.r = r;
-    }
-    sp.tile_b = 64 * sp.r;
-    const int Treal = (c.n + sp.tile_b - 1) / sp.tile_b;      // tiles that hold particles
-    const int SR = (Treal + 3) / 4;                            // super-rows of four target tiles
-    sp.tiles = SR * 4;                                         // padded tile count
-    sp.np = sp.tiles * sp.tile_b;
-    const int T = Treal, P = c.nranks;
-    // The choice between this plan and the one-sided source blocks must be the same on every rank (their
-    // partial sums are added): it may only depend on rank-independent quantities.  Fewer super-rows than
-    // ranks would leave a rank without work; the slab budget is checked for the worst case (every owned
-    // super-row cut into four pieces).
-    const size_t el = s->is_f64 ? sizeof(double) : sizeof(float);
-    if (SR < P) return NB_OK;
-    if ((size_t)c.dim * sp.np * el * (size_t)(4 * ((SR + P - 1) / P)) > (size_t)48 << 30) return NB_OK;
-    std::vector<int> ord(SR, -1), slot0(sp.tiles, 0), nslots(sp.tiles, 0);
-    long long owned_pairs = 0;
-    int nrows = 0;
-    for (int S = 0; S < SR; ++S) {
-        const int k = S % (2 * P);
-        const int owner = k < P ? k : 2 * P - 1 - k;           // snake: equal pair counts per rank
-        if (owner == c.rank) {
-            ord[S] = nrows++;
-            for (int w = 0; w < 4; ++w) owned_pairs += std::max(0, T - (4 * S + w));
-        }
-    }
-    // A workgroup sweeps 4 rows x cl source tiles.  ~2000 workgroups per launch: with tail smoothing
-    // (below) measured at N=65536 (R=4): cl = 1/2/4/6/8/16 -> step 1.28/1.28/1.27/1.29/1.29/1.47 ms
-    // (small cl pays in row-slot traffic, large cl in load balance).
-    int cl = (int)(owned_pairs / 2048 / 4);
-    cl = std::max(1, std::min(cl, 16));
-    if (const char *e = getenv("NB_SYM_CL")) cl = std::max(1, atoi(e));
-    // Tail smoothing.  Work items (4 rows x cl source tiles) all take the same time and the chip runs
-    // `slots` workgroups at once (4 per CU at <= 128 VGPRs), so items beyond a multiple of `slots` cost
-    // a whole extra round on a few CUs (measured: 1040 items on 1024 slots -> 0.21 instead of 0.16 ms).
-    // The sweeps of just enough trailing super-rows are therefore cut into 4 pieces of 16 rotation
-    // steps (a piece starts with the source tile pre-rotated, see force_sym_kernel); only those
-    // super-rows pay the extra slab / slot traffic.
-    int dev_cus = 256;
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) dev_cus = prop.multiProcessorCount; }
-    const long long wg_slots = 4LL * dev_cus;
-    std::vector<int> nch_of(SR, 0), split_of(SR, 1);
-    long long items = 0;
-    for (int S = 0; S < SR; ++S)
-        if (ord[S] >= 0) { nch_of[S] = (T - 4 * S + cl - 1) / cl; items += nch_of[S]; }
-    int force_split = 0;
-    if (const char *e = getenv("NB_SYM_SPLIT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) force_split = v; }
-    if (force_split) {
-        for (int S = 0; S < SR; ++S) split_of[S] = force_split;
-    } else if (items > wg_slots / 2) {
-        long long rem = items % wg_slots;
-        if (rem > 0 && rem <= wg_slots / 2) {
-            for (int S = SR - 1; S >= 0 && rem > 0; --S)      // trailing (shortest) super-rows first
-                if (ord[S] >= 0) { split_of[S] = 4; rem -= nch_of[S]; }
-        }
-    }
-    std::vector<SymWork> work;
-    std::vector<int> col_upto(sp.tiles, 0);   // slab entries [0, col_upto[J]) hold contributions to tile J
-    int slots = 0, ncol = 0;
-    for (int S = 0; S < SR; ++S) {
-        if (ord[S] < 0) continue;
-        const int j0 = 4 * S;
-        const int nch = nch_of[S], nsp = split_of[S];
-        const int per_row = nch * nsp;
-        for (int w = 0; w < 4; ++w) { slot0[j0 + w] = slots + w * per_row; nslots[j0 + w] = per_row; }
-        for (int ch = 0; ch < nch; ++ch)
-            for (int q = 0; q < nsp; ++q) {
-                SymWork wk{j0, j0 + ch * cl, std::min(T, j0 + (ch + 1) * cl), slots + ch * nsp + q, per_row,
-                           ncol + q, q * (64 / nsp), 64 / nsp};
-                work.push_back(wk);
-            }
-        slots += 4 * per_row;
-        ncol += nsp;
-    }
-    // slab entries are numbered in ascending super-row order, so the entries a tile needs -- those of the
-    // owned super-rows strictly above it, plus its own super-row when it is not the first tile of it --
-    // form a prefix of the index space
-    {
-        std::vector<int> first(SR + 1, 0);      // first[S] = entries of owned super-rows < S
-        for (int S = 0; S < SR; ++S) first[S + 1] = first[S] + (ord[S] >= 0 ? split_of[S] : 0);
-        for (int J = 0; J < sp.tiles; ++J) col_upto[J] = first[(J >> 2) + ((J & 3) ? 1 : 0)];
-    }
-    // whole sweeps first, pieces last (longest processing time first)
-    std::stable_sort(work.begin(), work.end(), [](const SymWork &a, const SymWork &b) {
-        return (long long)(a.jt_end - a.jt_begin) * a.s_count > (long long)(b.jt_end - b.jt_begin) * b.s_count;
-    });
-    const size_t col_bytes = (size_t)c.dim * sp.np * el * (size_t)std::max(ncol, 1);
-    sp.nwork = (int)work.size();
-    sp.nslots = slots;
-    if (sp.nwork == 0) return fail(NB_ERR_INVALID, "symmetric plan without work on rank %d", c.rank);
-    HIPCHK(hipMalloc((void **)&sp.work, work.size() * sizeof(SymWork)));
+    PlanInput in;
+    in.n = c.n; in.dim = c.dim; in.mode = c.mode; in.flags = c.flags; in.rank = c.rank; in.nranks = c.nranks;
+    in.is_f64 = s->is_f64;
+    in.multi = comm_active(s);
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) in.cus = prop.multiProcessorCount; }
+    SymPlanHost h;
+    nb_plan_sym(in, s->knobs, h);
+    if (!h.enabled) return NB_OK;
+    sp.r = h.r; sp.tile_b = h.tile_b; sp.tiles = h.tiles; sp.np = h.np;
+    sp.nwork = (int)h.work.size();
+    sp.nslots = h.nslots;
+    sp.chunk_work = h.chunk_work;
+    sp.chunk_tile = h.chunk_tile;
+    HIPCHK(hipMalloc((void **)&sp.work, h.work.size() * sizeof(SymWork)));
     HIPCHK(hipMalloc((void **)&sp.row_slot0, sp.tiles * sizeof(int)));
     HIPCHK(hipMalloc((void **)&sp.row_nslots, sp.tiles * sizeof(int)));
     HIPCHK(hipMalloc((void **)&sp.col_upto, sp.tiles * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&sp.packed, (size_t)(c.dim + 1) * sp.np * el));
-    HIPCHK(hipMalloc((void **)&sp.rowslab, (size_t)c.dim * sp.tile_b * sizeof(double) * (size_t)std::max(slots, 1)));
-    HIPCHK(hipMalloc((void **)&sp.colslab, col_bytes));
-    HIPCHK(hipMemcpy(sp.work, work.data(), work.size() * sizeof(SymWork), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp.row_slot0, slot0.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp.row_nslots, nslots.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp.col_upto, col_upto.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&sp.packed, h.packed_bytes));
+    if (sp.chunk_tile.size() > 2) HIPCHK(hipMalloc((void **)&sp.packed_alt, h.packed_bytes));
+    HIPCHK(hipMalloc((void **)&sp.rowslab, h.row_bytes));
+    HIPCHK(hipMalloc((void **)&sp.colslab, h.col_bytes));
+    HIPCHK(hipMemcpy(sp.work, h.work.data(), h.work.size() * sizeof(SymWork), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp.row_slot0, h.row_slot0.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp.row_nslots, h.row_nslots.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp.col_upto, h.col_upto.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
     sp.enabled = true;
     return NB_OK;
 }
@@ -537,7 +460,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
             // tab->r2max_bits is 0 here: zeroed at creation, put back by grid_tables_kernel after each use.
             // Small systems scan all pairs in one launch; the pruned search (six launches, O(N) + candidates^2)
             // pays off above that.
-            const bool prune = !getenv("NB_NO_PRUNE") && c.n > 8192;
+            const bool prune = !s->knobs.no_prune && c.n > 8192;
             if (prune) {
                 // every rank finds the global maximum itself: O(N) + (outer candidates)^2, no collective
                 HIPCHK(nb_launch_r2max_pruned((const float *)s->pos, c.n, c.dim, eps2, s->prune_cand, s->prune_rho,
@@ -629,6 +552,108 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
     return NB_OK;
 }
 
+// ---- chunked multi-GPU step ------------------------------------------------------
+// The owned super-rows are swept in C chunks of ascending super-row index.  After chunk c the sums of the
+// tiles below chunk_tile[c+1] are complete on this rank, so their reduction, their slice of the per-step RCCL
+// all-reduce and their kicks + drift + repack run on a separate high-priority stream while the force
+// streams sweep the remaining super-rows.  Chunk boundaries are identical on every rank (nb_plan.cpp).
+bool chunked_ok(const nb_sim *s)
+{
+    const int sdt = s->is_f64 ? NB_F64 : NB_F32;
+    return s->comm && s->sym.enabled && s->sym.chunk_tile.size() > 2 && s->sym.packed_alt && !grid_mode(s->cfg.mode) &&
+           s->logical[0] == sdt && s->logical[1] == sdt && s->logical[3] == sdt && s->have_acc;
+}
+
+int ensure_chunk_streams(nb_sim *s)
+{
+    if (s->cstream) return NB_OK;
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(hipStreamCreateWithPriority(&s->cstream, hipStreamNonBlocking, greatest));
+    HIPCHK(hipStreamCreateWithPriority(&s->fstream2, hipStreamNonBlocking, least));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+    for (auto &e : s->ev_force) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return NB_OK;
+}
+
+int launch_sym_range(nb_sim *s, const void *packed, int w0, int nw, hipStream_t st)
+{
+    if (nw <= 0) return NB_OK;
+    const nb_config &c = s->cfg;
+    const auto &sp = s->sym;
+    if (s->is_f64) {
+        HIPCHK(nb_launch_force_sym_f64((const double *)packed, sp.work + w0, nw, sp.rowslab, (double *)sp.colslab, sp.np,
+                                       c.dim, sp.r, s->mass_uniform, 0, c.softening_sq, st));
+        s->last_kernel = "force_sym_kernel<double";
+    } else {
+        const int hook = c.mode == NB_BFLOAT16 ? HOOK_BF16 : (c.mode == NB_FLOAT16 ? HOOK_F16 : HOOK_NONE);
+        HIPCHK(nb_launch_force_sym_f32((const float *)packed, sp.work + w0, nw, sp.rowslab, (float *)sp.colslab, sp.np,
+                                       c.dim, sp.r, s->mass_uniform, hook, (float)c.softening_sq, s->tab, (float)c.G,
+                                       (float)s->mass_value, 0, st));
+        s->last_kernel = "force_sym_kernel<float";
+    }
+    return NB_OK;
+}
+
+// `nsteps` leapfrog steps; on entry the accelerations are complete and, if pending_close, the closing half
+// kick of the previous step is still due.  On exit everything is applied and the main stream has joined.
+int step_chunked(nb_sim *s, int nsteps, bool pending_close)
+{
+    if (int rc = ensure_chunk_streams(s)) return rc;
+    const nb_config &c = s->cfg;
+    auto &sp = s->sym;
+    const int C = (int)sp.chunk_tile.size() - 1;
+    const double half_dt = c.dt / 2;
+    const double gfac = s->is_f64 ? c.G : (double)(float)c.G;
+    const size_t el = s->is_f64 ? 8 : 4;
+    double scale = 1.0;
+    if (s->mass_uniform) scale = s->is_f64 ? c.G * s->mass_value : (double)((float)c.G * (float)s->mass_value);
+    // opening kick + drift + pack of the first step (whole range, main stream)
+    HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, s->is_f64, pending_close ? 2 : 1,
+                          half_dt, c.dt, gfac, 0, s->stream));
+    for (int t = 0; t < nsteps; ++t) {
+        const bool last = (t + 1 == nsteps);
+        HIPCHK(hipEventRecord(s->ev_ready, s->stream));
+        HIPCHK(hipStreamWaitEvent(s->fstream2, s->ev_ready, 0));
+        HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_ready, 0));
+        for (int ch = 0; ch < C; ++ch) {
+            hipStream_t fs = (ch & 1) ? s->fstream2 : s->stream;
+            if (int rc = launch_sym_range(s, sp.packed, sp.chunk_work[ch], sp.chunk_work[ch + 1] - sp.chunk_work[ch], fs)) return rc;
+            HIPCHK(hipEventRecord(s->ev_force[ch], fs));
+        }
+        for (int ch = 0; ch < C; ++ch) {
+            const int p0 = sp.chunk_tile[ch] * sp.tile_b;
+            const int p1 = std::min(sp.chunk_tile[ch + 1] * sp.tile_b, c.n);
+            HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_force[ch], 0));
+            if (p1 > p0) {
+                HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.col_upto, sp.tile_b, c.n,
+                                            sp.np, c.dim, s->is_f64, scale, s->acc, s->vel, half_dt, 0, s->pos, sp.packed,
+                                            c.dt, s->cstream, p0, p1));
+                char *a = (char *)s->acc + (size_t)p0 * c.dim * el;
+                NCCLCHK(g_rccl.AllReduce(a, a, (size_t)(p1 - p0) * c.dim, s->is_f64 ? ncclDouble : ncclFloat, ncclSum, s->comm,
+                                         s->cstream));
+            }
+            if (!last) {
+                // closing kick, the next step's opening kick + drift, repack into the other buffer (the force
+                // streams may still be reading this step's positions from sp.packed)
+                const int pe = (ch == C - 1) ? sp.np : sp.chunk_tile[ch + 1] * sp.tile_b;
+                HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed_alt, c.n, sp.np, c.dim, s->is_f64, 2, half_dt,
+                                      c.dt, gfac, 0, s->cstream, p0, pe));
+            } else if (p1 > p0) {
+                HIPCHK(nb_launch_axpy((char *)s->vel + (size_t)p0 * c.dim * el, (char *)s->acc + (size_t)p0 * c.dim * el,
+                                      half_dt, (int64_t)(p1 - p0) * c.dim, s->is_f64, s->cstream));
+            }
+        }
+        HIPCHK(hipEventRecord(s->ev_done, s->cstream));
+        HIPCHK(hipStreamWaitEvent(s->stream, s->ev_done, 0));
+        HIPCHK(hipStreamWaitEvent(s->fstream2, s->ev_done, 0));
+        if (!last) std::swap(sp.packed, sp.packed_alt);
+    }
+    s->logical[3] = acc_logical_dtype(s);
+    return NB_OK;
+}
+
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(dev); }
@@ -671,6 +696,7 @@ int nb_create(nb_sim **out, const nb_config *cfg)
     if (cfg->device < 0 || cfg->device >= ndev) return fail(NB_ERR_NO_DEVICE, "device %d out of range [0,%d)", cfg->device, ndev);
     nb_sim *s = new nb_sim();
     s->cfg = *cfg;
+    s->knobs = nb_read_knobs();
     DeviceGuard guard(cfg->device);
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
         delete s;
@@ -686,16 +712,19 @@ int nb_destroy(nb_sim *s)
     if (!s) return NB_OK;
     DeviceGuard guard(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
+    s->comm = nullptr;              // borrowed from the process (nb_comm_shutdown destroys it)
     for (void *p : {s->pos, s->vel, s->mass, s->acc, (void *)s->partial, s->staging, (void *)s->tab,
                     (void *)s->scratch, (void *)s->scalars, (void *)s->fbins, (void *)s->sym.work,
                     (void *)s->sym.row_slot0, (void *)s->sym.row_nslots, (void *)s->sym.col_upto,
-                    (void *)s->sym.packed, (void *)s->sym.rowslab, (void *)s->sym.colslab,
+                    (void *)s->sym.packed, (void *)s->sym.packed_alt, (void *)s->sym.rowslab, (void *)s->sym.colslab,
                     (void *)s->prune_cand, (void *)s->prune_rho, (void *)s->prune_state})
         if (p) (void)hipFree(p);
     if (s->prof_init)
         for (int i = 0; i < PROF_RING; ++i) { (void)hipEventDestroy(s->ev_start[i]); (void)hipEventDestroy(s->ev_stop[i]); }
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    for (hipEvent_t e : {s->ev_ready, s->ev_done, s->ev_force[0], s->ev_force[1], s->ev_force[2], s->ev_force[3]})
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : {s->fstream2, s->cstream, s->stream})
+        if (st) (void)hipStreamDestroy(st);
     delete s;
     return NB_OK;
 }
@@ -734,7 +763,7 @@ int nb_set_state(nb_sim *s, const void *pos, const void *vel, const void *mass, 
         HIPCHK(nb_launch_minmax_generic(s->mass, s->is_f64, s->cfg.n, 0, 0.0, s->scalars + 4, s->scalars + 8, s->stream));
         HIPCHK(hipMemcpyAsync(mm, s->scalars + 4, sizeof mm, hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
-        s->mass_uniform = (mm[0] == mm[1]) && std::isfinite(mm[0]) && !getenv("NB_NO_UNIFORM");
+        s->mass_uniform = (mm[0] == mm[1]) && std::isfinite(mm[0]) && !s->knobs.no_uniform;
         s->mass_value = mm[0];
     }
     return NB_OK;
@@ -811,6 +840,8 @@ int nb_step(nb_sim *s, int32_t nsteps)
     bool opened = false;            // the previous step's reduction already did this step's opening kick + drift
     bool packed_by_prev = false;    // ... and repacked the positions for the symmetric kernel
     for (int t = 0; t < nsteps; ++t) {
+        // multi-GPU, pair-symmetric, settled dtypes: the remaining steps run as pipelined chunks
+        if (!opened && chunked_ok(s)) return step_chunked(s, nsteps - t, pending_close);
         // opening kick + drift; on the pair-symmetric path the repack rides in the same launch
         const int sdt = s->is_f64 ? NB_F64 : NB_F32;
         const bool fuse_pack = s->sym.enabled && s->logical[0] == sdt && s->logical[1] == sdt &&
@@ -860,7 +891,7 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential)
         if (!s->have_pos || !s->have_mass) return fail(NB_ERR_INVALID, "positions/masses not set");
         const auto &sp = s->sym;
         const bool pe_sym = sp.enabled && hp_x < 0 && (sp.r == 2 || sp.r == 4) && (size_t)sp.nwork <= s->scratch_elems &&
-                            !getenv("NB_NO_PE_SYM");
+                            !s->knobs.no_pe_sym;
         if (pe_sym) {
             // same tile-pair work list as the force kernel; `packed` is scratch between force evaluations
             HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, s->is_f64, 0, 0.0, 0.0,
@@ -1047,16 +1078,81 @@ int nb_comm_unique_id(void *id_out, int32_t *id_bytes)
 
 int nb_comm_init(nb_sim *s, const void *id, int32_t id_bytes)
 {
-    if (!s || !id) return fail(NB_ERR_INVALID, "null argument");
-    if (id_bytes != (int32_t)sizeof(ncclUniqueId)) return fail(NB_ERR_INVALID, "bad id size %d", id_bytes);
-    if (int rc = load_rccl()) return rc;
-    DeviceGuard guard(s->cfg.device);
-    ncclUniqueId uid;
-    memcpy(&uid, id, sizeof uid);
-    if (s->cfg.flags & NB_FLAG_SHARD_TIMING)       // one process stands in for one of nranks shards
-        NCCLCHK(g_rccl.CommInitRank(&s->comm, 1, uid, 0));
-    else
-        NCCLCHK(g_rccl.CommInitRank(&s->comm, s->cfg.nranks, uid, s->cfg.rank));
+    if (!s) return fail(NB_ERR_INVALID, "null handle");
+    // NB_FLAG_SHARD_TIMING: one process stands in for one of nranks shards on a 1-rank communicator
+    const int want_n = (s->cfg.flags & NB_FLAG_SHARD_TIMING) ? 1 : s->cfg.nranks;
+    const int want_r = (s->cfg.flags & NB_FLAG_SHARD_TIMING) ? 0 : s->cfg.rank;
+    std::lock_guard<std::mutex> lock(g_pc_mu);
+    if (!g_pc.comm) {
+        if (!id) return fail(NB_ERR_COMM, "no process communicator yet: the first nb_comm_init needs a unique id");
+        if (id_bytes != (int32_t)sizeof(ncclUniqueId)) return fail(NB_ERR_INVALID, "bad id size %d", id_bytes);
+        if (int rc = load_rccl()) return rc;
+        DeviceGuard guard(s->cfg.device);
+        ncclUniqueId uid;
+        memcpy(&uid, id, sizeof uid);
+        ncclComm_t comm = nullptr;
+        NCCLCHK(g_rccl.CommInitRank(&comm, want_n, uid, want_r));
+        g_pc.comm = comm;
+        g_pc.nranks = want_n;
+        g_pc.rank = want_r;
+        g_pc.device = s->cfg.device;
+    }
+    if (g_pc.nranks != want_n || g_pc.rank != want_r || g_pc.device != s->cfg.device)
+        return fail(NB_ERR_COMM, "the process communicator is rank %d of %d on device %d; this handle wants rank %d of %d "
+                                 "on device %d (one process drives one GPU)",
+                    g_pc.rank, g_pc.nranks, g_pc.device, want_r, want_n, s->cfg.device);
+    s->comm = g_pc.comm;
+    return NB_OK;
+}
+
+int nb_comm_ready(void)
+{
+    std::lock_guard<std::mutex> lock(g_pc_mu);
+    return g_pc.comm ? g_pc.nranks : 0;
+}
+
+int nb_comm_shutdown(void)
+{
+    std::lock_guard<std::mutex> lock(g_pc_mu);
+    if (!g_pc.comm) return NB_OK;
+    DeviceGuard guard(g_pc.device);
+    (void)hipDeviceSynchronize();
+    ncclComm_t comm = g_pc.comm;
+    g_pc = ProcComm();
+    if (g_rccl.CommDestroy) NCCLCHK(g_rccl.CommDestroy(comm));
+    return NB_OK;
+}
+
+// ---- planning without a device ---------------------------------------------------------------
+int nb_plan_debug(const nb_config *cfg, int32_t is_f64, int32_t multi, int32_t cus, int32_t info[16], int32_t *work,
+                  int64_t work_capacity, int32_t *row_slot0, int32_t *row_nslots, int32_t *col_upto,
+                  int32_t *chunk_work, int32_t *chunk_tile)
+{
+    if (!cfg || !info) return fail(NB_ERR_INVALID, "null argument");
+    if (cfg->n < 1 || (cfg->dim != 2 && cfg->dim != 3) || cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks)
+        return fail(NB_ERR_INVALID, "bad configuration");
+    PlanInput in;
+    in.n = cfg->n; in.dim = cfg->dim; in.mode = cfg->mode; in.flags = cfg->flags; in.rank = cfg->rank; in.nranks = cfg->nranks;
+    in.is_f64 = is_f64 != 0;
+    in.multi = multi != 0;
+    in.cus = cus > 0 ? cus : 256;
+    SymPlanHost h;
+    nb_plan_sym(in, nb_read_knobs(), h);
+    const int nchunks = h.enabled ? (int)h.chunk_tile.size() - 1 : 0;
+    const int32_t vals[16] = {h.enabled, h.r, h.tile_b, h.tiles, h.np, (int32_t)h.work.size(), h.nslots, h.ncol, h.cl, nchunks,
+                              (int32_t)(h.col_bytes >> 20), (int32_t)(h.row_bytes >> 20), 0, 0, 0, 0};
+    memcpy(info, vals, sizeof vals);
+    if (!h.enabled) return NB_OK;
+    if (work) {
+        if (work_capacity < (int64_t)h.work.size()) return fail(NB_ERR_INVALID, "work buffer too small (%zu items)", h.work.size());
+        static_assert(sizeof(SymWork) == 8 * sizeof(int32_t), "SymWork is eight ints");
+        memcpy(work, h.work.data(), h.work.size() * sizeof(SymWork));
+    }
+    if (row_slot0) memcpy(row_slot0, h.row_slot0.data(), h.tiles * sizeof(int32_t));
+    if (row_nslots) memcpy(row_nslots, h.row_nslots.data(), h.tiles * sizeof(int32_t));
+    if (col_upto) memcpy(col_upto, h.col_upto.data(), h.tiles * sizeof(int32_t));
+    if (chunk_work) memcpy(chunk_work, h.chunk_work.data(), (nchunks + 1) * sizeof(int32_t));
+    if (chunk_tile) memcpy(chunk_tile, h.chunk_tile.data(), (nchunks + 1) * sizeof(int32_t));
     return NB_OK;
 }
 

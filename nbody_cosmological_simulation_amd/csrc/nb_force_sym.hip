@@ -460,10 +460,10 @@ template <> __device__ __forceinline__ float axpy_rn<float>(float a, float b, fl
 template <typename T, int D, int KICK>
 __global__ void __launch_bounds__(NB_BLOCK)
 pack_kernel(T *__restrict__ pos, T *__restrict__ vel, const T *__restrict__ acc, const T *__restrict__ mass,
-            T *__restrict__ packed, int n, int np, T half_dt, T dt, T gfac, T pad)
+            T *__restrict__ packed, int n, int np, T half_dt, T dt, T gfac, T pad, int p_begin, int p_end)
 {
-    const int p = blockIdx.x * NB_BLOCK + threadIdx.x;
-    if (p >= np) return;
+    const int p = p_begin + blockIdx.x * NB_BLOCK + threadIdx.x;
+    if (p >= p_end) return;
     if (p < n) {
 #pragma unroll
         for (int k = 0; k < D; ++k) {
@@ -500,15 +500,16 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
                   const int *__restrict__ row_slot0, const int *__restrict__ row_nslots,
                   const int *__restrict__ col_upto, int tile_b, int n, int np,
                   double scale, T *__restrict__ acc, T *__restrict__ vel, T half_dt, int do_kick,
-                  T *__restrict__ pos, T *__restrict__ packed, T dt)
+                  T *__restrict__ pos, T *__restrict__ packed, T dt, int blk0)
 {
     __shared__ double s_part[NB_RED_WAVES][D][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + lane;
+    const int blk = blk0 + blockIdx.x;              // blocks [blk0, blk0 + gridDim.x): one pipeline chunk's tiles
+    const int p = blk * 64 + lane;
     const int pc = p < n ? p : n - 1;
-    const int J = (blockIdx.x * 64) / tile_b;       // block-uniform: tile_b is a multiple of 64
+    const int J = (blk * 64) / tile_b;              // block-uniform: tile_b is a multiple of 64
     const int s0 = row_slot0[J], ns = row_nslots[J], total = ns + col_upto[J];
-    const int off = blockIdx.x * 64 + lane - J * tile_b;
+    const int off = blk * 64 + lane - J * tile_b;
     double s[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) s[k] = 0.0;
@@ -688,15 +689,18 @@ hipError_t launch_sym_u(const T *packed, const SymWork *work, int nwork, double 
 
 hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mass, void *packed, int n, int np,
                           int dim, int is_f64, int kick, double half_dt, double dt, double gfac, int f32_pairs,
-                          hipStream_t st)
+                          hipStream_t st, int p_begin, int p_end)
 {
+    if (p_end < 0) p_end = np;
+    if (p_end <= p_begin) return hipSuccess;
     // padding coordinate: far enough that r^-3 vanishes, close enough that r2 stays finite in the
     // arithmetic the pair loop uses (fp32 pair arithmetic on fp64 storage needs the fp32 value)
     const double pad = (is_f64 && !f32_pairs) ? 1e150 : 1e18;
-    const int grid = (np + NB_BLOCK - 1) / NB_BLOCK;
+    const int grid = (p_end - p_begin + NB_BLOCK - 1) / NB_BLOCK;
 #define NB_PACK(TT, DD, KK) \
     hipLaunchKernelGGL((pack_kernel<TT, DD, KK>), dim3(grid), dim3(NB_BLOCK), 0, st, (TT *)pos, (TT *)vel, \
-                       (const TT *)acc, (const TT *)mass, (TT *)packed, n, np, (TT)half_dt, (TT)dt, (TT)gfac, (TT)pad)
+                       (const TT *)acc, (const TT *)mass, (TT *)packed, n, np, (TT)half_dt, (TT)dt, (TT)gfac, (TT)pad, \
+                       p_begin, p_end)
 #define NB_PACK_K(TT, DD) do { if (kick == 2) NB_PACK(TT, DD, 2); else if (kick == 1) NB_PACK(TT, DD, 1); else NB_PACK(TT, DD, 0); } while (0)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64) { if (dim == 2) NB_PACK_K(double, 2); else NB_PACK_K(double, 3); }
@@ -775,13 +779,16 @@ hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int 
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
                                 const int *row_nslots, const int *col_upto, int tile_b, int n,
                                 int np, int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
-                                int do_kick, void *pos, void *packed, double dt, hipStream_t st)
+                                int do_kick, void *pos, void *packed, double dt, hipStream_t st, int p_begin, int p_end)
 {
-    const int grid = (n + 63) / 64;
+    if (p_end < 0 || p_end > n) p_end = n;
+    if (p_end <= p_begin) return hipSuccess;
+    const int blk0 = p_begin / 64;                  // chunk boundaries are tile boundaries (multiples of 64)
+    const int grid = (p_end + 63) / 64 - blk0;
 #define NB_RED(TT, DD) \
     hipLaunchKernelGGL((reduce_sym_kernel<TT, DD>), dim3(grid), dim3(64 * NB_RED_WAVES), 0, st, rowslab, (const TT *)colslab, \
                        row_slot0, row_nslots, col_upto, tile_b, n, np, scale, (TT *)acc, (TT *)vel, (TT)half_dt, do_kick, \
-                       (TT *)pos, (TT *)packed, (TT)dt)
+                       (TT *)pos, (TT *)packed, (TT)dt, blk0)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64) { if (dim == 2) NB_RED(double, 2); else NB_RED(double, 3); }
     else        { if (dim == 2) NB_RED(float, 2); else NB_RED(float, 3); }

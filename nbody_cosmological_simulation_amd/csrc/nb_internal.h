@@ -88,7 +88,7 @@ struct NbKernelEvents {
 // kick + drift of a step (simulation.py:132,135)
 hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mass, void *packed, int n, int np,
                           int dim, int is_f64, int kick, double half_dt, double dt, double gfac, int f32_pairs,
-                          hipStream_t st);
+                          hipStream_t st, int p_begin = 0, int p_end = -1 /* packed entries [p_begin, p_end); -1 = np */);
 hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, int nwork, double *rowslab,
                                    double *colslab, int np, int dim, int r, int uniform, int pa_f32, double eps2,
                                    hipStream_t st, NbKernelEvents ev = {});
@@ -103,7 +103,8 @@ hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, cons
                                 const int *row_nslots, const int *col_upto, int tile_b, int n,
                                 int np, int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
                                 int do_kick /* 1: closing kick, 2: + next opening kick + drift + repack */,
-                                void *pos, void *packed, double dt, hipStream_t st);
+                                void *pos, void *packed, double dt, hipStream_t st,
+                                int p_begin = 0, int p_end = -1 /* particles [p_begin, p_end); -1 = n */);
 
 // ---- kernel launchers (implemented in the .hip files) --------------------------------------
 // T = storage/accumulation type of the state (float or double); pa_f32 != 0 selects fp32

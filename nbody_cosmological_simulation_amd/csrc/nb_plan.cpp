@@ -1,0 +1,197 @@
+// nb_plan.cpp -- work list of the pair-symmetric kernels (see nb_plan.h).  No HIP calls in this file.
+#include "nb_plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+namespace {
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+}  // namespace
+
+NbKnobs nb_read_knobs()
+{
+    NbKnobs k;
+    k.sym = env_int("NB_SYM", -1);
+    k.sym_r = env_int("NB_SYM_R", 0);
+    k.sym_cl = std::max(0, env_int("NB_SYM_CL", 0));
+    k.sym_split = env_int("NB_SYM_SPLIT", 0);
+    if (k.sym_split != 1 && k.sym_split != 2 && k.sym_split != 4 && k.sym_split != 8) k.sym_split = 0;
+    k.tail_pieces = env_int("NB_SYM_TAIL", 0);
+    if (k.tail_pieces != 2 && k.tail_pieces != 4 && k.tail_pieces != 8 && k.tail_pieces != 16) k.tail_pieces = 0;
+    k.chunks = std::min(4, std::max(0, env_int("NB_CHUNKS", 0)));
+    k.r_onesided = env_int("NB_R", 0);
+    k.no_prune = getenv("NB_NO_PRUNE") != nullptr;
+    k.no_pe_sym = getenv("NB_NO_PE_SYM") != nullptr;
+    k.no_uniform = getenv("NB_NO_UNIFORM") != nullptr;
+    k.no_smalln = getenv("NB_NO_SMALLN") != nullptr;
+    return k;
+}
+
+// Rows (target tiles) are grouped into super-rows of four (one per wave of a workgroup); super-rows are
+// dealt to the ranks in a snake pattern so every rank owns the same number of tile pairs to within one
+// super-row; each owned super-row is cut into work items of `cl` source tiles = one workgroup each.
+void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
+{
+    sp = SymPlanHost();
+    const int n = in.n, dim = in.dim, P = in.nranks;
+    const bool is_f64 = in.is_f64;
+    // Small systems: the pair-symmetric kernel has too few work items to fill the chip (one 64-step sweep per
+    // wave is its floor: ~50 us per step with tiles of 256 at any N <= 8192) and the one-sided LDS kernel wins.
+    // Between the two regimes a finer tiling (R = 2: tiles of 128, four times the work items, sweeps a quarter
+    // as long) fills the chip earlier: measured fp64 us per step, one-sided / R = 2 / R = 4: N = 6144 38.9 / 30.8 /
+    // 51.5, 8192 47.4 / 44.5 / 52.1, 12288 113 / 66.5 / 81.0, 16384 149 / 107 / 118, 20480 - / 154 / 152, 32768 - /
+    // 366 / 310; fp32: N = 4096 18.6 / 16.1 / 37.0, 8192 40.2 / 26.4 / 38.3, 16384 118 / 61.4 / 70.8, 24576 269 / 118 / 105.
+    // And at the very small end (fp64, 2-D) tiles of 64 (R = 1: one 64-step sweep of single pairs per wave, ~4 us)
+    // beat the one-sided kernel: 12.1 vs 16.6 us per step at N = 1024, 13.1 vs 18.3 at 2560, 18.1 vs 18.7 at 3000.
+    const bool tiny = is_f64 && dim == 2 && n <= 2816;
+    // fp32 family: R = 2 already wins at N = 1024 (14.2 vs 15.4 us; INT4 51 vs 62).  3-D crosses over later
+    // (fp64: 8192 56.9 one-sided vs 60.5, 12288 131 vs 92.6; fp32: 3000 19.8 vs 20.0, 8192 52.3 vs 36.0).
+    const int sym_from = dim == 3 ? (is_f64 ? 10240 : 4096) : (is_f64 ? 5120 : 1024);
+    int want = (tiny || n >= sym_from) ? 1 : 0;
+    if (knobs.sym >= 0) want = knobs.sym;
+    // comm-less shards (NB_FLAG_NO_COMM) use the one-sided kernel unless NB_SYM=2 asks for the symmetric
+    // plan of their rank (tests: the partial sums of all ranks' plans must add up to the full result)
+    if (!want || ((in.flags & NB_FLAG_NO_COMM) && want < 2)) return;
+    if (is_f64 && in.mode != NB_FLOAT64) return;    // fp64 state under a cast / grid mode: one-sided kernel
+    // targets per lane.  Measured on MI355X, N=65536, D=2: R=1 3.39 ms, R=2 1.87 ms, R=4 1.47 ms.  D=3 also keeps
+    // four targets per lane and sweeps the source tile in two halves of two slots (sym_rj, nb_force_sym.hip)
+    sp.r = tiny ? 1 : (n < 20480) ? 2 : 4;
+    if ((knobs.sym_r == 1 && is_f64 && dim == 2) || knobs.sym_r == 2 || knobs.sym_r == 4) sp.r = knobs.sym_r;
+    sp.tile_b = 64 * sp.r;
+    const int T = (n + sp.tile_b - 1) / sp.tile_b;            // tiles that hold particles
+    const int SR = (T + 3) / 4;                               // super-rows of four target tiles
+    sp.tiles = SR * 4;                                        // padded tile count
+    sp.np = sp.tiles * sp.tile_b;
+    // The choice between this plan and the one-sided source blocks must be the same on every rank (their
+    // partial sums are added): it may only depend on rank-independent quantities.  Fewer super-rows than
+    // ranks would leave a rank without work; the slab budget is checked for the worst case (every owned
+    // super-row cut into eight pieces).
+    const size_t el = is_f64 ? sizeof(double) : sizeof(float);
+    if (SR < P) return;
+    {
+        const long long rows_max = (SR + P - 1) / P;            // owned super-rows of the busiest rank
+        const long long entries_max = knobs.sym_split ? rows_max * knobs.sym_split
+                                                      : rows_max + 7 * std::min<long long>(rows_max, 2LL * in.cus);
+        if ((size_t)dim * sp.np * el * (size_t)entries_max > (size_t)48 << 30) return;
+    }
+
+    std::vector<int> ord(SR, -1);
+    sp.row_slot0.assign(sp.tiles, 0);
+    sp.row_nslots.assign(sp.tiles, 0);
+    long long owned_pairs = 0;
+    int nrows = 0;
+    for (int S = 0; S < SR; ++S) {
+        const int k = S % (2 * P);
+        const int owner = k < P ? k : 2 * P - 1 - k;           // snake: equal pair counts per rank
+        if (owner == in.rank) {
+            ord[S] = nrows++;
+            for (int w = 0; w < 4; ++w) owned_pairs += std::max(0, T - (4 * S + w));
+        }
+    }
+    // A workgroup sweeps 4 rows x cl source tiles.  ~2000 workgroups per launch: with tail smoothing
+    // (below) measured at N=65536 (R=4): cl = 1/2/4/6/8/16 -> step 1.28/1.28/1.27/1.29/1.29/1.47 ms
+    // (small cl pays in row-slot traffic, large cl in load balance).
+    int cl = (int)(owned_pairs / 2048 / 4);
+    cl = std::max(1, std::min(cl, 16));
+    if (knobs.sym_cl > 0) cl = knobs.sym_cl;
+    sp.cl = cl;
+
+    // ---- pipeline chunks (multi-GPU step): rank-independent super-row boundaries ----------------------
+    // Tiles below 4*B are complete once every owned super-row below B has been swept, so the reduction +
+    // all-reduce + kicks of that prefix can run while the remaining super-rows are still being computed.
+    // Only worth it when the remaining work outlasts a small all-reduce (tens of us over xGMI).
+    const double cyc_pair = (is_f64 ? 76.0 : 41.0) * (dim == 3 ? 19.0 / 14.0 : 1.0);
+    const double sweep_us = 64.0 * sp.r * sp.r * cyc_pair / 2200.0;                      // one wave, whole SIMD
+    const double force_us = ((double)T * (T + 1) / 2 / P) * sweep_us / (4.0 * in.cus);
+    int C = 1;
+    if (in.multi) C = knobs.chunks > 0 ? knobs.chunks : (force_us >= 400.0 ? 2 : 1);
+    if (SR < 2 * C) C = 1;
+    std::vector<int> bound(C + 1, 0);
+    bound[C] = SR;
+    if (C > 1) {
+        const double u = std::min(0.5, std::max(0.12, std::sqrt(80.0 / std::max(force_us, 1.0))));   // tile share of the last chunk
+        for (int c = 0; c + 1 < C; ++c) {
+            const double rem = std::pow(u, (double)(c + 1) / (C - 1));
+            int B = (int)std::floor(SR * (1.0 - rem));
+            if (B >= 2 * P) B -= B % (2 * P);                   // whole snake periods: equal shares per rank
+            bound[c + 1] = std::min(SR - (C - 1 - c), std::max(bound[c] + 1, B));
+        }
+    }
+    sp.chunk_tile.resize(C + 1);
+    for (int c = 0; c <= C; ++c) sp.chunk_tile[c] = 4 * bound[c];
+
+    // ---- tail smoothing -------------------------------------------------------------------------------
+    // Work items (4 rows x cl source tiles) all take the same time and the chip runs `slots` workgroups at
+    // once (4 per CU at <= 128 VGPRs), so items beyond a multiple of `slots` cost a whole extra round on a
+    // few CUs (measured: 1040 items on 1024 slots -> 0.21 instead of 0.16 ms).  The sweeps of just enough
+    // trailing super-rows are therefore cut into pieces of 16 (or 8) rotation steps (a piece starts with the
+    // source tile pre-rotated, see force_sym_kernel); only those super-rows pay the extra slab / slot traffic.
+    const long long wg_slots = 4LL * in.cus;
+    std::vector<int> nch_of(SR, 0), split_of(SR, 1);
+    long long items = 0;
+    for (int S = 0; S < SR; ++S)
+        if (ord[S] >= 0) { nch_of[S] = (T - 4 * S + cl - 1) / cl; items += nch_of[S]; }
+    if (knobs.sym_split) {
+        for (int S = 0; S < SR; ++S) split_of[S] = knobs.sym_split;
+    } else if (items > wg_slots / 2) {
+        long long rem = items % wg_slots;
+        // a single round of workgroups has nothing to hide a straggler behind: finer pieces there
+        const int pieces = knobs.tail_pieces ? knobs.tail_pieces : (items < 2 * wg_slots ? 8 : 4);
+        if (rem > 0 && rem <= wg_slots / 2) {
+            for (int S = SR - 1; S >= 0 && rem > 0; --S)      // trailing (shortest) super-rows first
+                if (ord[S] >= 0) { split_of[S] = pieces; rem -= nch_of[S]; }
+        }
+    }
+
+    // ---- work items, slots, slab entries ---------------------------------------------------------------
+    std::vector<int> chunk_of(SR, 0);
+    for (int c = 0; c < C; ++c)
+        for (int S = bound[c]; S < bound[c + 1]; ++S) chunk_of[S] = c;
+    struct Item { SymWork w; int chunk; };
+    std::vector<Item> items_v;
+    int slots = 0, ncol = 0;
+    for (int S = 0; S < SR; ++S) {
+        if (ord[S] < 0) continue;
+        const int j0 = 4 * S;
+        const int nch = nch_of[S], nsp = split_of[S];
+        const int per_row = nch * nsp;
+        for (int w = 0; w < 4; ++w) { sp.row_slot0[j0 + w] = slots + w * per_row; sp.row_nslots[j0 + w] = per_row; }
+        for (int ch = 0; ch < nch; ++ch)
+            for (int q = 0; q < nsp; ++q) {
+                SymWork wk{j0, j0 + ch * cl, std::min(T, j0 + (ch + 1) * cl), slots + ch * nsp + q, per_row,
+                           ncol + q, q * (64 / nsp), 64 / nsp};
+                items_v.push_back({wk, chunk_of[S]});
+            }
+        slots += 4 * per_row;
+        ncol += nsp;
+    }
+    // slab entries are numbered in ascending super-row order, so the entries a tile needs -- those of the
+    // owned super-rows strictly above it, plus its own super-row when it is not the first tile of it --
+    // form a prefix of the index space
+    sp.col_upto.assign(sp.tiles, 0);
+    {
+        std::vector<int> first(SR + 1, 0);      // first[S] = entries of owned super-rows < S
+        for (int S = 0; S < SR; ++S) first[S + 1] = first[S] + (ord[S] >= 0 ? split_of[S] : 0);
+        for (int J = 0; J < sp.tiles; ++J) sp.col_upto[J] = first[(J >> 2) + ((J & 3) ? 1 : 0)];
+    }
+    // chunk by chunk; inside a chunk whole sweeps first, pieces last (longest processing time first)
+    std::stable_sort(items_v.begin(), items_v.end(), [](const Item &a, const Item &b) {
+        if (a.chunk != b.chunk) return a.chunk < b.chunk;
+        return (long long)(a.w.jt_end - a.w.jt_begin) * a.w.s_count > (long long)(b.w.jt_end - b.w.jt_begin) * b.w.s_count;
+    });
+    sp.work.reserve(items_v.size());
+    sp.chunk_work.assign(C + 1, 0);
+    for (const Item &it : items_v) { sp.work.push_back(it.w); sp.chunk_work[it.chunk + 1]++; }
+    for (int c = 0; c < C; ++c) sp.chunk_work[c + 1] += sp.chunk_work[c];
+    sp.nslots = slots;
+    sp.ncol = ncol;
+    sp.col_bytes = (size_t)dim * sp.np * el * (size_t)std::max(ncol, 1);
+    sp.row_bytes = (size_t)dim * sp.tile_b * sizeof(double) * (size_t)std::max(slots, 1);
+    sp.packed_bytes = (size_t)(dim + 1) * sp.np * el;
+    sp.enabled = !sp.work.empty();
+}

@@ -1,11 +1,14 @@
 """Process-level runtime context: which HIP device this process drives and, under
 `torch.distributed` (one process per GPU), which block of sources it owns.
 
-Multi-GPU layout (DESIGN.md "multi-GPU"): every rank holds the full O(N) state, computes
-partial accelerations of ALL targets over its contiguous source block
-[rank*N/P, (rank+1)*N/P) and the per-particle force vectors are summed with one RCCL
-all-reduce per step inside libnbody_amd (nb_comm_init).  torch.distributed is plumbing only:
-it carries the 128-byte RCCL unique id from rank 0 to the other ranks.
+Multi-GPU layout (DESIGN.md "multi-GPU"): every rank holds the full O(N) state and computes
+partial accelerations of ALL particles over its share of the pair work -- snake-dealt target
+super-rows of the pair-symmetric kernel (the partition at every benchmark size), or a contiguous
+source block [rank*N/P, (rank+1)*N/P) on the one-sided kernels (small N, fp64 state under a cast
+mode) -- and the per-particle force vectors are summed with one RCCL all-reduce per step inside
+libnbody_amd.  torch.distributed is plumbing only: it carries the 128-byte RCCL unique id from
+rank 0 to the other ranks, once per process: all simulations of a process share ONE communicator
+(nb_comm_init), which only `shutdown()` destroys (collective; never a garbage collector).
 """
 import ctypes as C
 import os
@@ -50,6 +53,32 @@ def reset_distributed():
     _ctx.update(rank=0, world=1, device=None, group=None)
 
 
+def partition_label(world: int = None) -> str:
+    """Human-readable name of the pair-work partition (bench.py / logs)."""
+    world = _ctx["world"] if world is None else world
+    if world <= 1:
+        return "single GPU"
+    return (f"snake-dealt target super-rows (pair-symmetric) x{world}; one-sided kernels: source j-blocks "
+            f"+ one RCCL all-reduce of the force vectors per step")
+
+
+def attach_communicator(handle):
+    """Give `handle` the process communicator, creating it on first use (collective: every rank creates its
+    first communicating simulation at the same point of the program, like any other collective)."""
+    L = N.lib()
+    if L.nb_comm_ready() > 0:
+        N.check(L.nb_comm_init(handle, None, 0))
+        return
+    uid = exchange_unique_id()
+    N.check(L.nb_comm_init(handle, uid, len(uid)))
+
+
+def shutdown():
+    """Destroy the process communicator (collective).  Call on every rank after the last step and before
+    torch.distributed is torn down; simulations created afterwards would need a new communicator."""
+    N.check(N.lib().nb_comm_shutdown())
+
+
 def rank_world():
     return _ctx["rank"], _ctx["world"]
 
@@ -57,7 +86,7 @@ def rank_world():
 def force_comm() -> bool:
     """NBODY_FORCE_COMM=1: create the RCCL communicator even for one rank, so a single-GPU box
     exercises nb_comm_init and the all-reduce calls of the multi-GPU step."""
-    return os.environ.get("NBODY_FORCE_COMM", "0") == "1" and _ctx["world"] >= 1 and _dist_ready()
+    return os.environ.get("NBODY_FORCE_COMM", "0") == "1"
 
 
 def _dist_ready() -> bool:
@@ -74,6 +103,8 @@ def _draw_unique_id() -> bytes:
 
 def exchange_unique_id(draw=_draw_unique_id) -> bytes:
     """Rank 0 draws an RCCL unique id (nb_comm_unique_id); everyone receives its bytes."""
+    if _ctx["world"] <= 1 and not _dist_ready():
+        return draw()                       # a 1-rank communicator needs no transport
     import torch.distributed as dist
     payload = [None]
     if _ctx["rank"] == 0:

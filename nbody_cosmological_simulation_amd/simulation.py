@@ -97,8 +97,7 @@ class GalaxySimulation:
             flags=flags)
         N.check(N.lib().nb_create(C.byref(self._handle), C.byref(cfg)))
         if shard is None and (world > 1 or runtime.force_comm()):
-            uid = runtime.exchange_unique_id()
-            N.check(N.lib().nb_comm_init(self._handle, uid, len(uid)))
+            runtime.attach_communicator(self._handle)      # one communicator per process, shared
 
         # simulation.py:63-65: clone -> device.  The clone is the upload itself.
         self._upload("positions", positions)
@@ -134,9 +133,8 @@ class GalaxySimulation:
 
     # ------------------------------------------------------------------ native plumbing
     def close(self):
-        """Release the native handle (device buffers, stream, RCCL communicator) now instead of at garbage
-        collection.  Multi-GPU: collective -- every rank closes its simulations in the same order, before
-        torch.distributed is torn down."""
+        """Release the native handle (device buffers, streams) now instead of at garbage collection.  Never a
+        collective: the RCCL communicator belongs to the process (runtime.shutdown() destroys it)."""
         h = getattr(self, "_handle", None)
         if h is not None and h.value:
             try:

@@ -406,30 +406,40 @@ def test_errors_are_exceptions(nb):
 
 def test_rccl_path_with_one_rank_communicator():
     """The multi-GPU step (nb_comm_init + RCCL all-reduce of forces / r2max / PE) exercised on one
-    GPU with a 1-rank communicator: results must be bit-identical to the comm-less path."""
+    GPU with a 1-rank communicator: results must be bit-identical to the comm-less path -- also when the
+    step runs as 2 / 3 / 4 pipelined chunks (prefix reductions + sliced all-reduce on the collective stream,
+    double-buffered packed positions), and all simulations of the process share ONE communicator."""
     import subprocess
     import sys
     script = r'''
-import os, sys, socket
+import os, sys
 sys.path.insert(0, os.environ["NB_ROOT"])
-import numpy as np, torch, torch.distributed as dist
+import numpy as np, torch
 import nbody_cosmological_simulation_amd as nb
-from nbody_cosmological_simulation_amd import runtime, galaxy
+from nbody_cosmological_simulation_amd import runtime, galaxy, _native
 pos, vel, mass = galaxy.create_disk_galaxy(9000, seed=5, device="cpu")   # pair-symmetric path (tiles of 128) + deferred kick
-def run(mode):
+modes = (nb.PrecisionMode.FLOAT64, nb.PrecisionMode.FLOAT32, nb.PrecisionMode.FLOAT16, nb.PrecisionMode.INT4_SIM)
+def run(mode, steps=(3, 2)):
     s = nb.GalaxySimulation(pos, vel, mass, precision_mode=mode)
-    s.run(3)
-    return s.positions.numpy().copy(), s.get_total_energy()
-base = {m: run(m) for m in (nb.PrecisionMode.FLOAT64, nb.PrecisionMode.INT4_SIM)}
-sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    for k in steps:                      # two native calls: the second starts from settled dtypes
+        s.run(k)
+    out = s.positions.numpy().copy(), s.velocities.numpy().copy(), s.get_total_energy()
+    s.close()
+    return out
+base = {m: run(m) for m in modes}
 os.environ["NBODY_FORCE_COMM"] = "1"
 runtime.init_distributed(device=0)
-for m, (p0, e0) in base.items():
-    p1, e1 = run(m)
-    assert np.array_equal(p0, p1), m
-    assert e0 == e1, m
-dist.destroy_process_group()
+assert _native.lib().nb_comm_ready() == 0
+for chunks in ("1", "2", "3", "4"):
+    os.environ["NB_CHUNKS"] = chunks
+    for m, (p0, v0, e0) in base.items():
+        p1, v1, e1 = run(m)
+        assert np.array_equal(p0, p1), (m, chunks)
+        assert np.array_equal(v0, v1), (m, chunks)
+        assert e0 == e1, (m, chunks)
+    assert _native.lib().nb_comm_ready() == 1          # one communicator for all of them
+runtime.shutdown()
+assert _native.lib().nb_comm_ready() == 0
 print("RCCL-1RANK-OK")
 '''
     env = dict(os.environ, NB_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -443,8 +453,6 @@ print("RCCL-1RANK-OK")
 def test_pair_symmetric_kernel_vs_oracle(nb, monkeypatch, n, d, r, uniform):
     """The pair-symmetric fp64 kernel (nb_force_sym.hip) forced on for ragged / small sizes."""
     from oracle import oracle as O
-    if r == 4 and d == 3:
-        pytest.skip("R=4 is compiled for D=2 only")
     monkeypatch.setenv("NB_SYM", "1")
     monkeypatch.setenv("NB_SYM_R", str(r))
     rng = np.random.default_rng(n + d + r)
