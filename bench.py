@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--mode", default="float64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample length")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch plumbing only: rendezvous (gloo when there is no GPU), barrier, one JSON line; no HIP work")
     ap.add_argument("--ref-sizes", default="1024,4096,8192",
                     help="sizes at which the reference's materialised torch formulation is timed (SURVEY.md 8d); '' = skip")
     return ap.parse_args()
@@ -78,16 +80,36 @@ def self_launch(args):
     return proc.returncode
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota when one is set
+    (a 1-GPU box of the pool exposes 128 logical CPUs but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(pos, vel, mass, target_s, ref_sizes, gpu_drift):
     """Oracle (C port of the reference algorithm, all host cores) on a bounded sample of the bench workload;
     `gpu_drift(steps)` returns the GPU engine's relative energy drift over the same steps from the same ICs."""
     import numpy as np
+    cores = host_cores()
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))       # before the oracle's OpenMP runtime starts
     from oracle import oracle as O
     p = np.ascontiguousarray(pos.double().numpy())
     v = np.ascontiguousarray(vel.double().numpy())
     m = np.ascontiguousarray(mass.double().numpy())
     n, d = p.shape
     lib = O.lib()
+    try:                                  # torch has usually started the OpenMP runtime already: set it directly
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
     acc = np.empty_like(p)
     t0 = time.perf_counter()
     lib.nbo_accelerations_f64_fast(n, d, O._dp(p), O._dp(m), 0.001, 0.1 ** 2, 0, n, O._dp(acc))
@@ -111,7 +133,7 @@ def cpu_baseline(pos, vel, mass, target_s, ref_sizes, gpu_drift):
     try:
         import torch
         from oracle import torch_materialised as TM
-        threads = torch.get_num_threads()
+        threads = min(torch.get_num_threads(), cores)
         for nr in ref_sizes:
             for mode in ("float64", "float32"):
                 rt, used = TM.time_steps(pos[:nr].clone(), vel[:nr].clone(), mass[:nr].clone(), steps=10, warmup=10,
@@ -121,7 +143,7 @@ def cpu_baseline(pos, vel, mass, target_s, ref_sizes, gpu_drift):
     except Exception as exc:            # never let the context measurement break the bench line
         ref_form.append({"error": repr(exc)})
     return {
-        "value": n * steps / dt, "unit": "particle-steps/s", "cores": O.num_threads(), "kind": "port",
+        "value": n * steps / dt, "unit": "particle-steps/s", "cores": O.num_threads(), "host_cores_available": cores, "kind": "port",
         "sample": f"N={n} fp64 disk galaxy, {steps} leapfrog steps of the oracle's OpenMP fast path "
                   f"({dt:.1f} s; the reference's own PyTorch formulation cannot run at this N)",
         "pair_interactions_per_s": float(n) * n * steps / dt,
@@ -163,6 +185,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        if "RANK" in os.environ:
+            dist.init_process_group(backend="gloo")
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            assert int(t.item()) == world
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "gpus_arg": args.gpus}), flush=True)
+        return 0 if args.gpus == world else 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)

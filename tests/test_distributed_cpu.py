@@ -183,3 +183,17 @@ def test_plan_choice_is_rank_independent():
             for is_f64 in (True, False):
                 en = {_plan(n, 2, r, world, is_f64=is_f64)["enabled"] for r in range(world)}
                 assert len(en) == 1, (n, world, is_f64)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without RANK in the environment must start the N ranks itself (child
+    torch.distributed.run, rendezvous on 127.0.0.1) and relay rank 0's JSON line -- the driver's command shape."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"dry_run": True, "n_gpus": 2, "gpus_arg": 2}
