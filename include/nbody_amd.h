@@ -132,11 +132,13 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential);
 
 /* Grid-mode internals of the LAST force evaluation: info[0..3] = lmin, lmax (log-grid of
  * quantization.py:109-113), fmin, fmax (linear force grid, quantization.py:78-79);
- * info[4] = max r^2 over all pairs.  If d2bins != NULL (host, n*n int16, row i / column j)
+ * info[4] = max r^2 over all pairs; info[5] = 1 when the table-free pair path was enabled for that evaluation,
+ * info[6] = measured deviation of its bin estimate at the bin edges (in bins), info[7] = measured relative
+ * deviation of its force factors from the exact table entries (enabled only when <= 1e-6).  If d2bins != NULL (host, n*n int16, row i / column j)
  * the distance-bin index of every pair is recomputed on the device with the same tables the
  * force kernel used; fbins (host, n*dim int16) likewise for the force bins of INT8/INT4.
  * -1 marks "degenerate grid: value passed through" (quantization.py:115-116 / :81-82). */
-int nb_quant_debug(nb_sim *s, double info[5], int16_t *d2bins, int16_t *fbins);
+int nb_quant_debug(nb_sim *s, double info[8], int16_t *d2bins, int16_t *fbins);
 
 /* ---- tensor-level hooks (quantization.py module functions used by override subclasses) -- */
 

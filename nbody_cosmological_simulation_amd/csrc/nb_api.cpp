@@ -478,7 +478,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
                                              s->stream));
             }
             HIPCHK(nb_launch_grid_tables(s->tab, L, (float)c.G, eps2, 0.01f, prune ? s->prune_state : nullptr,
-                                         s->stream));
+                                         s->stream, s->knobs.no_grid_fast ? 0 : 1));
         }
         used_sym = s->sym.enabled && pa == NB_F32;
         if (used_sym) {
@@ -928,7 +928,7 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential)
     return NB_OK;
 }
 
-int nb_quant_debug(nb_sim *s, double info[5], int16_t *d2bins, int16_t *fbins)
+int nb_quant_debug(nb_sim *s, double info[8], int16_t *d2bins, int16_t *fbins)
 {
     if (!s) return fail(NB_ERR_INVALID, "null handle");
     if (!s->have_storage || s->is_f64 || !grid_mode(s->cfg.mode))
@@ -939,7 +939,10 @@ int nb_quant_debug(nb_sim *s, double info[5], int16_t *d2bins, int16_t *fbins)
     HIPCHK(hipMemcpyAsync(&h, s->tab, sizeof h, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipMemcpyAsync(mnmx, s->scalars, sizeof mnmx, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    if (info) { info[0] = h.lmin; info[1] = h.lmax; info[2] = mnmx[0]; info[3] = mnmx[1]; info[4] = h.r2max; }
+    if (info) {
+        info[0] = h.lmin; info[1] = h.lmax; info[2] = mnmx[0]; info[3] = mnmx[1]; info[4] = h.r2max;
+        info[5] = h.fast_ok; info[6] = h.fast_maxdev; info[7] = h.fast_maxrel;
+    }
     const int n = s->cfg.n;
     if (d2bins) {
         int16_t *dev = nullptr;

@@ -600,9 +600,10 @@ __device__ __forceinline__ float grid_bin_exact(float t, float min_val, float lm
 // tab->r2max_bits and written their entries) writes the scalars and resets the scratch for the next evaluation.
 __global__ void __launch_bounds__(NB_LUT_MIN)
 grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2, float min_val,
-                   PruneState *__restrict__ ps)
+                   PruneState *__restrict__ ps, int allow_fast)
 {
     __shared__ int s_last;
+    __shared__ float s_thr[NB_LUT_MIN], s_lut[NB_LUT_MIN], s_red[NB_LUT_MIN], s_par[4];
     const int k = blockIdx.x * NB_LUT_MIN + threadIdx.x;
     const float r2max = __uint_as_float(tab->r2max_bits);
     const float tmin = (eps2 < min_val) ? min_val : eps2;        // diagonal entries: r2 == eps2
@@ -652,6 +653,8 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
             }
         }
         tab->thr[k] = thr;
+        s_thr[threadIdx.x] = thr;
+        s_lut[threadIdx.x] = tab->lut[k];
     }
     __syncthreads();               // every thread of this block has read tab->r2max_bits and written its entry
     if (threadIdx.x == 0) {
@@ -661,6 +664,66 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
     __syncthreads();
     if (!s_last) return;
     const bool fin = threadIdx.x == 0;
+    // ---- table-free pair path: parameters + validation (single-block tables only: levels <= NB_LUT_MIN) ------
+    const double est_a_d = 0.6931471805599453 * (double)lm1 / (double)range;
+    const float est_a = (float)est_a_d, est_b = (float)(-(double)lmin * (double)lm1 / (double)range);
+    const bool est_ok = (range >= 1e-10f && est_a_d < 1.0e4);
+    const int kc = levels / 2;
+    const float est_bc = (float)(-(double)lmin * (double)lm1 / (double)range - (double)kc);
+    bool fast_try = allow_fast && est_ok && gridDim.x == 1 && levels >= 2 && r2max == r2max && r2max < 1e30f;
+    if (fin) {
+        // log2 of the force factor is affine in the bin index: fit it to the table's end points
+        const double w0 = (double)s_lut[0], w1 = (double)s_lut[min(levels, NB_LUT_MIN) - 1];
+        double c1 = 0.0, cm = 0.0;
+        if (fast_try && w0 > 0.0 && w1 > 0.0 && w0 < 1e30 && w1 < 1e30) {
+            c1 = (log2(w1) - log2(w0)) / (double)(levels - 1);
+            cm = log2(w0) + c1 * (double)kc;            // log2 of the factor of the middle bin
+        } else {
+            fast_try = false;
+        }
+        const double tm = rint(cm);
+        if (!(fabs(tm) < 100.0) || !(fabs(c1) * (double)levels < 100.0)) fast_try = false;
+        s_par[0] = (float)c1;
+        s_par[1] = (float)(cm - tm);
+        s_par[2] = (float)tm;
+        s_last = fast_try ? 2 : 1;
+    }
+    __syncthreads();
+    fast_try = (s_last == 2);
+    float my_dev = 0.0f, my_rel = 0.0f;
+    if (fast_try && k < levels) {
+        // the estimate exactly as the pair loop evaluates it, on both sides of the lower edge of bin k
+        if (k > 0) {
+            const float r = s_thr[k], rp = __uint_as_float(__float_as_uint(r) - 1u);
+            const float edge = (float)(k - kc) - 0.5f;
+            const float e1 = __builtin_fmaf(__builtin_amdgcn_logf(r), est_a, est_bc) - edge;
+            const float e0 = __builtin_fmaf(__builtin_amdgcn_logf(rp), est_a, est_bc) - edge;
+            my_dev = fmaxf(fabsf(e1), fabsf(e0));
+            if (!(my_dev == my_dev)) my_dev = 1.0f;
+        }
+        const float wf = __builtin_amdgcn_exp2f(__builtin_fmaf((float)(k - kc), s_par[0], s_par[1]));
+        const float wt = ldexpf(s_lut[k], -(int)s_par[2]);
+        my_rel = fabsf(wf - wt) / wt;
+        if (!(my_rel == my_rel)) my_rel = 1.0f;
+    }
+    float maxdev = 0.0f, maxrel = 0.0f;
+    if (fast_try) {                 // block-uniform
+        s_red[threadIdx.x] = my_dev;
+        __syncthreads();
+        for (int st = NB_LUT_MIN / 2; st >= 1; st >>= 1) {
+            if ((int)threadIdx.x < st) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + st]);
+            __syncthreads();
+        }
+        maxdev = s_red[0];
+        __syncthreads();
+        s_red[threadIdx.x] = my_rel;
+        __syncthreads();
+        for (int st = NB_LUT_MIN / 2; st >= 1; st >>= 1) {
+            if ((int)threadIdx.x < st) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + st]);
+            __syncthreads();
+        }
+        maxrel = s_red[0];
+    }
     if (fin && ps) {
         // the pruned max-r2 search is finished: reset its scratch for the next evaluation
         for (int c = 0; c < 3; ++c) { ps->box_min[c] = 0xffffffffu; ps->box_max[c] = 0u; }
@@ -678,10 +741,9 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
         // v_log_f32 is good to ~1e-6 absolute, so for a < 1e4 the estimate is within 0.01 bins of the
         // exact (monotone) formula and rint() of it is off by at most one bin, which two threshold
         // compares repair exactly.  Narrow grids (a >= 1e4) keep the binary search.
-        const double a = 0.6931471805599453 * (double)lm1 / (double)range;
-        tab->est_a = (float)a;
-        tab->est_b = (float)(-(double)lmin * (double)lm1 / (double)range);
-        tab->use_est = (range >= 1e-10f && a < 1.0e4) ? 1 : 0;
+        tab->est_a = est_a;
+        tab->est_b = est_b;
+        tab->use_est = est_ok ? 1 : 0;
         tab->lmin = lmin;
         tab->lmax = lmax;
         tab->range = range;
@@ -689,6 +751,22 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
         tab->degenerate = (range < 1e-10f) ? 1 : 0;
         tab->levels = levels;
         tab->uniform_ok = (tab->use_est && r2max < 1e30f) ? 1 : 0;   // false for NaN / inf r2max too
+        // v_log_f32 is good to 1 ulp of its result; inside a bin the estimate can therefore dip below its value at
+        // the bin's lower edge by 2 * a * ulp (taken twice here) plus the rounding of the fma (half an ulp of L)
+        const float lmag = fmaxf(fabsf(__builtin_amdgcn_logf(tmin)), fabsf(__builtin_amdgcn_logf(tmax)));
+        const float ulp_log = __uint_as_float((__float_as_uint(fmaxf(lmag, 1.0f)) & 0x7f800000u)) * 1.1920929e-7f;
+        const float ulp_ne = __uint_as_float((__float_as_uint((float)levels) & 0x7f800000u)) * 1.1920929e-7f;
+        const float eta = 4.0f * est_a * ulp_log + ulp_ne;
+        const float delta = 2.0f * (maxdev + eta);
+        tab->fast_ok = (fast_try && delta < 0.05f && maxrel <= 2.0e-6f) ? 1 : 0;
+        tab->sure_lim = 0.5f - delta;
+        tab->kc = kc;
+        tab->tm = (int)s_par[2];
+        tab->est_bc = est_bc;
+        tab->c1 = s_par[0];
+        tab->c0c = s_par[1];
+        tab->fast_maxdev = maxdev;
+        tab->fast_maxrel = maxrel;
         tab->r2max_bits = 0u;      // consumed (every thread read it on entry): ready for the next atomicMax round
     }
 }
@@ -836,10 +914,10 @@ hipError_t nb_launch_r2max_pruned(const float *pos, int n, int dim, float eps2, 
 }
 
 hipError_t nb_launch_grid_tables(GridTables *tab, int levels, float G, float eps2, float min_val, PruneState *ps,
-                                 hipStream_t st)
+                                 hipStream_t st, int allow_fast)
 {
     hipLaunchKernelGGL(grid_tables_kernel, dim3((levels + NB_LUT_MIN - 1) / NB_LUT_MIN), dim3(NB_LUT_MIN), 0, st, tab,
-                       levels, G, eps2, min_val, ps);
+                       levels, G, eps2, min_val, ps, allow_fast);
     return hipGetLastError();
 }
 

@@ -84,12 +84,19 @@ constexpr int sym_rj(int d, int r) { return (d == 3 && r == 4) ? 2 : r; }
 
 struct GridArgs {
     const float *thr, *lut;
-    const float4 *rec;      // rec[k] = {thr[k+1], lut[k], lut[k+1], -} for the one-access estimate path
     float est_a, est_b, gfac;
     int lmax_bin;
-    bool degenerate;
     int lp;                 // table size (power of two) for the binary-search fallback
+    // table-free path (GridTables::fast_ok): bin - kc = rint(centred estimate) when the estimate is further than
+    // sure_lim from a bin edge, scaled force factor = v_exp_f32((bin - kc) c1 + c0c)
+    float est_bc, sure_lim, c1, c0c, kcf;
 };
+// grid variants of the sweeps (template parameter EST): how a pair finds its force factor
+enum { GRID_SEARCH = 0,   // binary search over the thresholds (estimate unusable: very narrow grids)
+       GRID_EST = 2,      // floor(estimate) + one threshold compare + table value: two dependent LDS reads
+       GRID_FAST = 3,     // table-free (see GridArgs); falls back to GRID_EST for a wave with a pair near a bin edge
+       GRID_FAST_CLAMP = 4,   // ... with softening^2 below the grid's floor 0.01: estimates below bin 0 clamp to it
+       GRID_DEGENERATE = 5 }; // lmax - lmin < 1e-10: clamped values pass through (quantization.py:115-116)
 
 // One sweep of a target tile (R particles per lane) against RJ source slots: `nsteps` rotation steps (64 = all
 // lanes), R*RJ pairs per lane per step, J data rotating by one lane per step.  RJ = R covers the whole
@@ -143,11 +150,20 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
                     if (D == 3) r2 = __fadd_rn(r2, __fmul_rn(d[2], d[2]));
                     r2 = __fadd_rn(r2, eps2);
                     if (HOOK == HOOK_GRID) {
-                        if (ga.degenerate) {
+                        if (EST == GRID_DEGENERATE) {
                             w = inv_r3_sym((r2 < 0.01f) ? 0.01f : r2, c15, c1875) * ga.gfac;
-                        } else if (EST == 1) {
-                            w = grid_w_estimate(ga.rec, r2, ga.est_a, ga.est_b, ga.lmax_bin - 1);
-                        } else if (EST == 2) {
+                        } else if (EST == GRID_FAST || EST == GRID_FAST_CLAMP) {
+                            // table-free unless one of the wave's 64 pairs sits near a bin edge (see sweep_pk)
+                            const float ne = __builtin_fmaf(__builtin_amdgcn_logf(r2), ga.est_a, ga.est_bc);
+                            float kf = __builtin_rintf(ne);
+                            const float dev = __builtin_fabsf(ne - kf);
+                            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(dev <= ga.sure_lim)) != 0ull, 0)) {
+                                w = ga.lut[grid_bin_floor_estimate(ga.thr, r2, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
+                            } else {
+                                if (EST == GRID_FAST_CLAMP) kf = __builtin_amdgcn_fmed3f(kf, -ga.kcf, 1e30f);
+                                w = __builtin_amdgcn_exp2f(__builtin_fmaf(kf, ga.c1, ga.c0c));
+                            }
+                        } else if (EST == GRID_EST) {
                             w = ga.lut[grid_bin_floor_estimate(ga.thr, r2, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
                         } else {
                             w = ga.lut[grid_bin_lookup(ga.thr, r2, ga.lp)];   // (1/q^1.5)*G
@@ -216,13 +232,27 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                 r2 = r2 + eps2;
                 f2 w;
                 if (HOOK == HOOK_GRID) {
-                    if (ga.degenerate) {
+                    if (EST == GRID_DEGENERATE) {
                         w.x = inv_r3_sym((r2.x < 0.01f) ? 0.01f : r2.x, 1.5f, 0.0f) * ga.gfac;
                         w.y = inv_r3_sym((r2.y < 0.01f) ? 0.01f : r2.y, 1.5f, 0.0f) * ga.gfac;
-                    } else if (EST == 1) {
-                        w.x = grid_w_estimate(ga.rec, r2.x, ga.est_a, ga.est_b, ga.lmax_bin - 1);
-                        w.y = grid_w_estimate(ga.rec, r2.y, ga.est_a, ga.est_b, ga.lmax_bin - 1);
-                    } else if (EST == 2) {
+                    } else if (EST == GRID_FAST || EST == GRID_FAST_CLAMP) {
+                        // no table access for a wave whose 128 pairs all sit clear of the bin edges (the common case:
+                        // an edge zone is ~1e-4 of a bin wide); the estimate is the one grid_tables_kernel validated
+                        const f2 lg = {__builtin_amdgcn_logf(r2.x), __builtin_amdgcn_logf(r2.y)};
+                        const f2 ne = __builtin_elementwise_fma(lg, f2{ga.est_a, ga.est_a}, f2{ga.est_bc, ga.est_bc});
+                        f2 kf = {__builtin_rintf(ne.x), __builtin_rintf(ne.y)};
+                        const f2 fr = ne - kf;
+                        const float dev = __builtin_fmaxf(__builtin_fabsf(fr.x), __builtin_fabsf(fr.y));
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(dev <= ga.sure_lim)) != 0ull, 0)) {   // also taken for NaN
+                            w.x = ga.lut[grid_bin_floor_estimate(ga.thr, r2.x, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
+                            w.y = ga.lut[grid_bin_floor_estimate(ga.thr, r2.y, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
+                        } else {
+                            if (EST == GRID_FAST_CLAMP)
+                                kf = f2{__builtin_amdgcn_fmed3f(kf.x, -ga.kcf, 1e30f), __builtin_amdgcn_fmed3f(kf.y, -ga.kcf, 1e30f)};
+                            const f2 th = __builtin_elementwise_fma(kf, f2{ga.c1, ga.c1}, f2{ga.c0c, ga.c0c});
+                            w = f2{__builtin_amdgcn_exp2f(th.x), __builtin_amdgcn_exp2f(th.y)};
+                        }
+                    } else if (EST == GRID_EST) {
                         w.x = ga.lut[grid_bin_floor_estimate(ga.thr, r2.x, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
                         w.y = ga.lut[grid_bin_floor_estimate(ga.thr, r2.y, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
                     } else {
@@ -285,39 +315,44 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
     constexpr int lp = LPC;
     __shared__ float s_thr[HOOK == HOOK_GRID ? LPC + 1 : 1];
     __shared__ float s_lut[HOOK == HOOK_GRID ? LPC + 1 : 1];
-    __shared__ float4 s_rec[HOOK == HOOK_GRID ? NB_REC_LEVELS + 1 : 1];
 
     const SymWork wk = work[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int I = wk.tile_i + wave;             // this wave's target tile (wave-uniform)
     const int rot_addr = ((lane + 1) & 63) << 2;
-    GridArgs ga{s_thr, s_lut, s_rec, 0.0f, 0.0f, gfac, 0, false, lp};
-    bool use_est = false, few_levels = false;
+    GridArgs ga{s_thr, s_lut, 0.0f, 0.0f, gfac, 0, lp, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    bool use_est = false, fast = false, degenerate = false;
+    float gscale = gfac;      // uniform-mass grid kernel: factor applied to the finished sums (the common mass)
+    int mass_exp = 0;
     if (HOOK == HOOK_GRID) {
         const int levels = tab->levels;
         // uniform-mass grid kernel (gate 1) and its general-mass stand-in (gate 2) are launched as a
         // pair; the tables decide on the device which of the two does the work
         const int ok = tab->uniform_ok;
         if ((gate == 1 && !ok) || (gate == 2 && ok)) return;
-        // <= 32 levels: lanes mostly share records, the 16-byte record read broadcasts (one LDS access
-        // per pair).  More levels: random 16-byte reads saturate the LDS, two dependent 4-byte reads
-        // (threshold, then LUT value) are cheaper.
-        few_levels = levels <= NB_REC_LEVELS;
+        // table-free pairs produce factors scaled by 2^-tm (GridTables): the table copies are scaled alike
+        // (exact: a power of two) and the power of two goes back in with the common mass
+        fast = tab->fast_ok != 0;
+        const int tm = fast ? tab->tm : 0;
+        mass_exp = UNIFORM ? 0 : tm;          // general masses: the power of two rides on the mass factors instead
         for (int k = threadIdx.x; k <= lp; k += NB_BLOCK) {
             // binary search pads with +inf; the estimate path needs the NaN sentinel at thr[levels]
             s_thr[k] = (k <= levels) ? tab->thr[k] : __builtin_inff();
             // uniform masses: padding particles (r2 >= 1e36) are caught by one more "bin" of weight 0
             if (UNIFORM && k == levels) s_thr[k] = 1e35f;
-            s_lut[k] = (k < levels) ? tab->lut[k] : 0.0f;
+            s_lut[k] = (k < levels) ? ldexpf(tab->lut[k], -tm) : 0.0f;
         }
-        ga.degenerate = tab->degenerate != 0;
+        degenerate = tab->degenerate != 0;
         ga.est_a = tab->est_a;
         ga.est_b = tab->est_b;
         ga.lmax_bin = UNIFORM ? levels : levels - 1;
         use_est = tab->use_est != 0;
-        __syncthreads();
-        for (int k = threadIdx.x; k <= NB_REC_LEVELS; k += NB_BLOCK)     // lp >= NB_LUT_MIN > NB_REC_LEVELS + 1
-            s_rec[k] = make_float4(s_thr[k + 1], s_lut[k], s_lut[k + 1], 0.0f);
+        ga.est_bc = tab->est_bc;
+        ga.sure_lim = tab->sure_lim;
+        ga.c1 = tab->c1;
+        ga.c0c = tab->c0c;
+        ga.kcf = (float)tab->kc;
+        gscale = ldexpf(gfac, tm);
         __syncthreads();
     }
 
@@ -332,6 +367,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
             ai_sum[r][k] = 0.0;
         }
         gi[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
+        if constexpr (F32 && HOOK == HOOK_GRID && !UNIFORM) gi[r] = ldexpf(gi[r], mass_exp);
     }
 
     for (int J = wk.jt_begin; J < wk.jt_end; ++J) {     // all four waves take the same source tile
@@ -344,10 +380,12 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
             for (int k = 0; k < D; ++k) aj[r][k] = (T)0;
         if (J >= I) {                                   // wave-uniform; tiles below the diagonal belong to other rows
             const bool diag = (J == I);
-            if constexpr (F32 && (RJ % 2 == 0) && (HOOK != HOOK_GRID || UNIFORM)) {
-                // fp32 modes: source slots (2h, 2h+1) packed in float2 halves (sweep_pk).  The general-mass
-                // grid kernel keeps the scalar loop (the packed form spills there); the uniform-mass one
-                // always has a usable estimate (GridTables::uniform_ok gates it).
+            // fp32 modes: source slots (2h, 2h+1) packed in float2 halves (sweep_pk).  The general-mass grid kernel
+            // keeps the scalar loop (its packed form needs more than 128 VGPRs: measured 1.50 vs 1.24 ms per launch
+            // at N = 65536 with the spills inside the pair loop); the uniform-mass one always has a usable estimate
+            // (GridTables::uniform_ok gates it).
+            constexpr bool use_packed = F32 && (RJ % 2 == 0) && (HOOK != HOOK_GRID || UNIFORM);
+            if constexpr (use_packed) {
                 f2 xj2[RJ / 2][D], gj2[RJ / 2], aj2[RJ / 2][D], ai2[R][D];
 #pragma unroll
                 for (int h = 0; h < RJ / 2; ++h) {
@@ -364,16 +402,20 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                 for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int k = 0; k < D; ++k) ai2[r][k] = f2{0.0f, 0.0f};
-                if (HOOK == HOOK_GRID && few_levels) {
-                    if (diag) sweep_pk<D, R, RJ, true, UNIFORM, HOOK, 1>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
-                    else sweep_pk<D, R, RJ, false, UNIFORM, HOOK, 1>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+#define NB_SWEEP_PK(EE)                                                                                                   \
+    do {                                                                                                                 \
+        if (diag) sweep_pk<D, R, RJ, true, UNIFORM, HOOK, EE>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count); \
+        else sweep_pk<D, R, RJ, false, UNIFORM, HOOK, EE>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);     \
+    } while (0)
+                if (HOOK == HOOK_GRID && fast) {
+                    if (eps2 < 0.01f) NB_SWEEP_PK(GRID_FAST_CLAMP);
+                    else NB_SWEEP_PK(GRID_FAST);
                 } else if (HOOK == HOOK_GRID) {
-                    if (diag) sweep_pk<D, R, RJ, true, UNIFORM, HOOK, 2>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
-                    else sweep_pk<D, R, RJ, false, UNIFORM, HOOK, 2>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    NB_SWEEP_PK(GRID_EST);           // only reached with a usable estimate
                 } else {
-                    if (diag) sweep_pk<D, R, RJ, true, UNIFORM, HOOK, 0>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
-                    else sweep_pk<D, R, RJ, false, UNIFORM, HOOK, 0>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);
+                    NB_SWEEP_PK(0);
                 }
+#undef NB_SWEEP_PK
 #pragma unroll
                 for (int h = 0; h < RJ / 2; ++h)
 #pragma unroll
@@ -390,21 +432,23 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
 #pragma unroll
                     for (int k = 0; k < D; ++k) xj[r][k] = packed[(size_t)k * np + p];
                     gj[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
+                    if constexpr (F32 && HOOK == HOOK_GRID && !UNIFORM) gj[r] = ldexpf(gj[r], mass_exp);
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int k = 0; k < D; ++k) ai[r][k] = F32 ? (T)0 : (T)ai_sum[r][k];
-                if (HOOK == HOOK_GRID && use_est && few_levels) {
-                    if (diag) sweep<T, D, R, RJ, true, UNIFORM, HOOK, 1>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
-                    else sweep<T, D, R, RJ, false, UNIFORM, HOOK, 1>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
-                } else if (HOOK == HOOK_GRID && use_est) {
-                    if (diag) sweep<T, D, R, RJ, true, UNIFORM, HOOK, 2>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
-                    else sweep<T, D, R, RJ, false, UNIFORM, HOOK, 2>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
-                } else {
-                    if (diag) sweep<T, D, R, RJ, true, UNIFORM, HOOK, 0>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
-                    else sweep<T, D, R, RJ, false, UNIFORM, HOOK, 0>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);
-                }
+#define NB_SWEEP(EE)                                                                                                  \
+    do {                                                                                                                 \
+        if (diag) sweep<T, D, R, RJ, true, UNIFORM, HOOK, EE>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);     \
+        else sweep<T, D, R, RJ, false, UNIFORM, HOOK, EE>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);         \
+    } while (0)
+                if (HOOK == HOOK_GRID && degenerate) NB_SWEEP(GRID_DEGENERATE);
+                else if (HOOK == HOOK_GRID && fast && eps2 < (T)0.01) NB_SWEEP(GRID_FAST_CLAMP);
+                else if (HOOK == HOOK_GRID && fast) NB_SWEEP(GRID_FAST);
+                else if (HOOK == HOOK_GRID && use_est) NB_SWEEP(GRID_EST);
+                else NB_SWEEP(GRID_SEARCH);
+#undef NB_SWEEP
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -427,7 +471,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                 T v = s_aj[0][r][k][l];
 #pragma unroll
                 for (int w = 1; w < W; ++w) v += s_aj[w][r][k][l];
-                if (UNIFORM && HOOK == HOOK_GRID) v *= (T)gfac;      // gfac = the common mass here
+                if (UNIFORM && HOOK == HOOK_GRID) v *= (T)gscale;    // the common mass (times 2^tm on the table-free path)
                 colslab[((size_t)wk.col_ord * D + k) * np + (size_t)J * B + (hs + r) * 64 + l] = v;
             }
         }
@@ -442,7 +486,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
 #pragma unroll
         for (int k = 0; k < D; ++k)
             rowslab[((size_t)slot * D + k) * B + r * 64 + lane] =
-                (UNIFORM && HOOK == HOOK_GRID) ? ai_sum[r][k] * (double)gfac : ai_sum[r][k];
+                (UNIFORM && HOOK == HOOK_GRID) ? ai_sum[r][k] * (double)gscale : ai_sum[r][k];
 }
 
 // Padding particles sit at `pad` in every coordinate (chosen by nb_launch_pack): r^2 stays finite and

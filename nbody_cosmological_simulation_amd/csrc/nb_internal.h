@@ -34,6 +34,20 @@ struct GridTables {
     unsigned int blocks_done; // grid_tables_kernel: arrival counter of its blocks (the last one finalises)
     int uniform_ok;          // 1: the uniform-mass grid kernel may run (estimate usable, r2max far below the
                              //    padding distance, so "r2 >= 1e35" identifies padding particles)
+    // Table-free pair path.  A pair whose bin estimate sits further than `sure_lim` from
+    // a bin edge has bin rint(estimate) for certain; its force factor follows from the bin index alone:
+    // log2(lut[k]) is affine in k, so lut[k] * 2^-tm = v_exp_f32((k - kc) * c1 + c0c), with kc the middle bin and
+    // tm an integer that centres the exponent (both shrink the rounding of the fma; the power of two is put back
+    // exactly when the finished sums are scaled).  grid_tables_kernel fits c1 / c0c to the table itself,
+    // measures the estimate's deviation at EVERY bin edge and the factor's deviation from EVERY table entry
+    // (the reference's own fp32 evaluation of the bin values scatters them by ~1e-6 around the affine law),
+    // and only then sets fast_ok.
+    int fast_ok;
+    int kc, tm;
+    float est_bc;            // est_b - kc: the centred estimate rounds to k - kc directly
+    float sure_lim;          // 0.5 - delta: |estimate - rint(estimate)| at or below this -> bin is certain
+    float c1, c0c;
+    float fast_maxdev, fast_maxrel;   // measured: estimate deviation at the bin edges (bins), factor vs table (relative)
 };
 
 // table entries allocated in LDS for `levels` grid levels: next power of two, at least NB_LUT_MIN (the binary-search
@@ -125,7 +139,7 @@ hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float 
 hipError_t nb_launch_r2max_pruned(const float *pos, int n, int dim, float eps2, float *cand, float *rho,
                                   PruneState *ps, GridTables *tab, hipStream_t st);
 hipError_t nb_launch_grid_tables(GridTables *tab, int levels, float G, float eps2, float min_val,
-                                 PruneState *ps /* reset after use; may be null */, hipStream_t st);
+                                 PruneState *ps /* reset after use; may be null */, hipStream_t st, int allow_fast = 1);
 hipError_t nb_launch_d2bins(const float *pos, int n, int dim, float eps2, const GridTables *tab,
                             int16_t *bins, hipStream_t st);
 

@@ -29,6 +29,7 @@ NbKnobs nb_read_knobs()
     k.no_pe_sym = getenv("NB_NO_PE_SYM") != nullptr;
     k.no_uniform = getenv("NB_NO_UNIFORM") != nullptr;
     k.no_smalln = getenv("NB_NO_SMALLN") != nullptr;
+    k.no_grid_fast = getenv("NB_NO_GRID_FAST") != nullptr;
     return k;
 }
 

@@ -24,6 +24,7 @@ struct NbKnobs {
     bool no_pe_sym = false;  // NB_NO_PE_SYM: one-sided potential-energy kernel
     bool no_uniform = false; // NB_NO_UNIFORM: general-mass kernels even for equal masses
     bool no_smalln = false;  // NB_NO_SMALLN: never use the single-launch small-N step
+    bool no_grid_fast = false;   // NB_NO_GRID_FAST: grid modes always read their tables (A/B of the table-free pair path)
 };
 NbKnobs nb_read_knobs();
 

@@ -348,7 +348,7 @@ class GalaxySimulation:
     def quant_debug(self, bins: bool = False):
         """Grid internals of the last force evaluation (INT8/INT4/CUSTOM modes)."""
         import numpy as np
-        info = (C.c_double * 5)()
+        info = (C.c_double * 8)()
         n, d = self.num_stars, self._dim()
         d2 = np.empty((n, n), np.int16) if bins else None
         has_fq = self.precision_mode in (PrecisionMode.INT8_SIM, PrecisionMode.INT4_SIM)
@@ -356,7 +356,8 @@ class GalaxySimulation:
         N.check(N.lib().nb_quant_debug(self._handle, info,
                                        None if d2 is None else d2.ctypes.data_as(C.c_void_p),
                                        None if fb is None else fb.ctypes.data_as(C.c_void_p)))
-        return dict(lmin=info[0], lmax=info[1], fmin=info[2], fmax=info[3], r2max=info[4], d2bins=d2, fbins=fb)
+        return dict(lmin=info[0], lmax=info[1], fmin=info[2], fmax=info[3], r2max=info[4], d2bins=d2, fbins=fb,
+                    fast_path=bool(info[5]), fast_maxdev=info[6], fast_maxrel=info[7])
 
 
 def run_comparison(
