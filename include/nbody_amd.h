@@ -139,6 +139,8 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential);
  * force kernel used; fbins (host, n*dim int16) likewise for the force bins of INT8/INT4.
  * -1 marks "degenerate grid: value passed through" (quantization.py:115-116 / :81-82). */
 int nb_quant_debug(nb_sim *s, double info[8], int16_t *d2bins, int16_t *fbins);
+/* The same distance-bin indices for target rows [i0, i1) only (host, (i1-i0)*n int16): sizes where n*n is out of reach. */
+int nb_quant_bins_rows(nb_sim *s, int32_t i0, int32_t i1, int16_t *d2bins);
 
 /* ---- tensor-level hooks (quantization.py module functions used by override subclasses) -- */
 

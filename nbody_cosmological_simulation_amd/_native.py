@@ -26,7 +26,7 @@ MODE_CODES = {
 EXPORTS = [
     "nb_create", "nb_destroy", "nb_set_params", "nb_set_state", "nb_get_state", "nb_state_dtypes",
     "nb_set_accelerations", "nb_compute_accelerations", "nb_step", "nb_kick_drift", "nb_kick",
-    "nb_energy", "nb_quant_debug", "nb_quantize_distance_squared", "nb_quantize_force",
+    "nb_energy", "nb_quant_debug", "nb_quant_bins_rows", "nb_quantize_distance_squared", "nb_quantize_force",
     "nb_grid_quantize", "nb_grid_quantize_safe", "nb_comm_unique_id", "nb_comm_init", "nb_comm_ready",
     "nb_comm_shutdown", "nb_plan_debug",
     "nb_kernel_time", "nb_force_kernel_name", "nb_synchronize", "nb_device_count", "nb_abi_version", "nb_last_error",
@@ -77,6 +77,7 @@ def lib():
         "nb_kick": ([vp], C.c_int),
         "nb_energy": ([vp, pdbl, pdbl], C.c_int),
         "nb_quant_debug": ([vp, pdbl, vp, vp], C.c_int),
+        "nb_quant_bins_rows": ([vp, i32, i32, vp], C.c_int),
         "nb_quantize_distance_squared": ([C.c_int, vp, vp, i64, C.c_int, C.c_int, C.c_int, dbl, C.c_int, pi32], C.c_int),
         "nb_quantize_force": ([C.c_int, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, pi32], C.c_int),
         "nb_grid_quantize": ([C.c_int, vp, vp, i64, C.c_int, C.c_int, C.c_int], C.c_int),

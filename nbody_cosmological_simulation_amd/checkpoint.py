@@ -22,8 +22,8 @@ def state_hash(sim_or_positions, velocities: torch.Tensor = None) -> str:
         positions, velocities = sim_or_positions.positions, sim_or_positions.velocities
     else:
         positions = sim_or_positions
-    data = positions.detach().cpu().contiguous().numpy().tobytes() + \
-        velocities.detach().cpu().contiguous().numpy().tobytes()
+    # bfloat16 has no numpy dtype (upstream's .numpy() raises there): hash its raw 16-bit patterns
+    data = _np(positions)[0].tobytes() + _np(velocities)[0].tobytes()
     return hashlib.sha256(data).hexdigest()[:16]
 
 

@@ -928,6 +928,38 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential)
     return NB_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// distance-bin indices of rows [i0, i1) with the tables of the last evaluation, copied to the host
+int bins_rows(nb_sim *s, int i0, int i1, int16_t *host)
+{
+    const int n = s->cfg.n;
+    const size_t bytes = (size_t)(i1 - i0) * n * sizeof(int16_t);
+    int16_t *dev = nullptr;
+    HIPCHK(hipMalloc((void **)&dev, bytes));
+    hipError_t e = nb_launch_d2bins((const float *)s->pos, n, s->cfg.dim, (float)s->cfg.softening_sq, s->tab, dev, s->stream,
+                                    i0, i1);
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(dev);
+    HIPCHK(e);
+    return NB_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int nb_quant_bins_rows(nb_sim *s, int32_t i0, int32_t i1, int16_t *d2bins)
+{
+    if (!s || !d2bins) return fail(NB_ERR_INVALID, "null argument");
+    if (!s->have_storage || s->is_f64 || !grid_mode(s->cfg.mode))
+        return fail(NB_ERR_INVALID, "quant debug is only defined for the grid modes");
+    if (i0 < 0 || i1 > s->cfg.n || i0 >= i1) return fail(NB_ERR_INVALID, "bad row range [%d, %d)", i0, i1);
+    DeviceGuard guard(s->cfg.device);
+    return bins_rows(s, i0, i1, d2bins);
+}
+
 int nb_quant_debug(nb_sim *s, double info[8], int16_t *d2bins, int16_t *fbins)
 {
     if (!s) return fail(NB_ERR_INVALID, "null handle");
@@ -943,17 +975,8 @@ int nb_quant_debug(nb_sim *s, double info[8], int16_t *d2bins, int16_t *fbins)
         info[0] = h.lmin; info[1] = h.lmax; info[2] = mnmx[0]; info[3] = mnmx[1]; info[4] = h.r2max;
         info[5] = h.fast_ok; info[6] = h.fast_maxdev; info[7] = h.fast_maxrel;
     }
-    const int n = s->cfg.n;
-    if (d2bins) {
-        int16_t *dev = nullptr;
-        HIPCHK(hipMalloc((void **)&dev, (size_t)n * n * sizeof(int16_t)));
-        hipError_t e = nb_launch_d2bins((const float *)s->pos, n, s->cfg.dim, (float)s->cfg.softening_sq, s->tab, dev,
-                                        s->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d2bins, dev, (size_t)n * n * sizeof(int16_t), hipMemcpyDeviceToHost, s->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-        (void)hipFree(dev);
-        HIPCHK(e);
-    }
+    if (d2bins)
+        if (int rc = bins_rows(s, 0, s->cfg.n, d2bins)) return rc;
     if (fbins) {
         if (!s->fbins) return fail(NB_ERR_INVALID, "this mode does not quantise forces");
         HIPCHK(hipMemcpyAsync(fbins, s->fbins, (size_t)nd(s) * sizeof(int16_t), hipMemcpyDeviceToHost, s->stream));

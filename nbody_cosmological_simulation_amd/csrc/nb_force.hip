@@ -775,10 +775,10 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
 template <int D>
 __global__ void __launch_bounds__(NB_BLOCK)
 d2bins_kernel(const float *__restrict__ pos, int n, float eps2, const GridTables *__restrict__ tab,
-              int16_t *__restrict__ bins)
+              int16_t *__restrict__ bins, int i0)
 {
     const int j = blockIdx.x * NB_BLOCK + threadIdx.x;
-    const int i = blockIdx.y;
+    const int i = i0 + blockIdx.y;
     if (j >= n) return;
     float d[D];
 #pragma unroll
@@ -789,7 +789,7 @@ d2bins_kernel(const float *__restrict__ pos, int n, float eps2, const GridTables
         b = 0;
         for (int k = 1; k < tab->levels; ++k) b += (tab->thr[k] <= r2) ? 1 : 0;
     }
-    bins[(size_t)i * n + j] = (int16_t)b;
+    bins[(size_t)(i - i0) * n + j] = (int16_t)b;
 }
 
 template <typename F>
@@ -922,12 +922,13 @@ hipError_t nb_launch_grid_tables(GridTables *tab, int levels, float G, float eps
 }
 
 hipError_t nb_launch_d2bins(const float *pos, int n, int dim, float eps2, const GridTables *tab, int16_t *bins,
-                            hipStream_t st)
+                            hipStream_t st, int i0, int i1)
 {
-    const dim3 grid((n + NB_BLOCK - 1) / NB_BLOCK, n);
+    if (i1 < 0) i1 = n;
+    const dim3 grid((n + NB_BLOCK - 1) / NB_BLOCK, i1 - i0);
     return dispatch_dim(dim, [&](auto D) {
         constexpr int DD = decltype(D)::value;
-        hipLaunchKernelGGL((d2bins_kernel<DD>), grid, dim3(NB_BLOCK), 0, st, pos, n, eps2, tab, bins);
+        hipLaunchKernelGGL((d2bins_kernel<DD>), grid, dim3(NB_BLOCK), 0, st, pos, n, eps2, tab, bins, i0);
         return hipGetLastError();
     });
 }

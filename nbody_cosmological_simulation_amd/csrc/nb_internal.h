@@ -141,7 +141,7 @@ hipError_t nb_launch_r2max_pruned(const float *pos, int n, int dim, float eps2, 
 hipError_t nb_launch_grid_tables(GridTables *tab, int levels, float G, float eps2, float min_val,
                                  PruneState *ps /* reset after use; may be null */, hipStream_t st, int allow_fast = 1);
 hipError_t nb_launch_d2bins(const float *pos, int n, int dim, float eps2, const GridTables *tab,
-                            int16_t *bins, hipStream_t st);
+                            int16_t *bins, hipStream_t st, int i0 = 0, int i1 = -1 /* rows [i0, i1); -1 = n */);
 
 // reduce the S partial slabs in fixed order; optionally fuse the closing half kick
 hipError_t nb_launch_reduce(const double *partial, int nchunks, int64_t count, void *acc, int is_f64,

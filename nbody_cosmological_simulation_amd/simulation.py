@@ -359,6 +359,14 @@ class GalaxySimulation:
         return dict(lmin=info[0], lmax=info[1], fmin=info[2], fmax=info[3], r2max=info[4], d2bins=d2, fbins=fb,
                     fast_path=bool(info[5]), fast_maxdev=info[6], fast_maxrel=info[7])
 
+    def quant_bins_rows(self, i0: int, i1: int):
+        """Distance-bin indices of target rows [i0, i1) of the last force evaluation (grid modes), (i1-i0, N) int16."""
+        import numpy as np
+        out = np.empty((i1 - i0, self.num_stars), np.int16)
+        N.check(N.lib().nb_quant_bins_rows(self._handle, int(i0), int(i1), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
 
 def run_comparison(
     positions: torch.Tensor,

@@ -340,6 +340,71 @@ int nbo_accelerations(int n, int d, int P, const double *pos, int M, const doubl
     return A;
 }
 
+/* Rows [i0, i1) of the same evaluation at sizes where the full N x N pass is too slow for a test: the grid's
+ * global log-min/max still spans ALL n*n pairs (log is monotone, so they follow from the extreme r2 values, found
+ * without a log per pair); no force quantisation (it needs every row).  acc_out: (i1-i0)*d, d2bins: (i1-i0)*n. */
+int nbo_accelerations_rows(int n, int d, int P, const double *pos, int M, const double *mass,
+                           int mode, int levels, double G, double eps2_py, int i0, int i1,
+                           double *acc_out, double *dbg, int32_t *d2bins)
+{
+    const int grid = (mode >= NBO_INT8);
+    const int L = mode_levels(mode, levels);
+    const double min_val = 0.01;
+    int Q = P;
+    { double tmp = hook_simple(mode, P, 1.0, &Q); (void)tmp; }
+    if (grid) Q = P;
+    const int W = promote(Q, M);
+    const int W2 = promote(W, NBO_F32);
+    const int A = promote(W2, P);
+    double lmin = 0, lmax = 0;
+    int degenerate = 0;
+    if (grid) {
+        double rmin = INFINITY, rmax = -INFINITY;
+        int has_nan = 0;
+        #pragma omp parallel for reduction(min:rmin) reduction(max:rmax) reduction(|:has_nan) schedule(static)
+        for (int i = 0; i < n; ++i) {
+            double diff[4];
+            for (int j = 0; j < n; ++j) {
+                double r2 = pair_r2(P, d, pos + (long)i * d, pos + (long)j * d, eps2_py, diff);
+                if (isnan(r2)) has_nan = 1;
+                if (r2 < rmin) rmin = r2;
+                if (r2 > rmax) rmax = r2;
+            }
+        }
+        lmin = has_nan ? NAN : gqs_log(P, rmin, min_val);
+        lmax = has_nan ? NAN : gqs_log(P, rmax, min_val);
+        degenerate = (rnd(P, lmax - lmin) < 1e-10);
+    }
+    if (dbg) { dbg[0] = lmin; dbg[1] = lmax; dbg[2] = 0; dbg[3] = 0; }
+    const double Gs = scalar_as(Q, G);
+    #pragma omp parallel for schedule(static)
+    for (int i = i0; i < i1; ++i) {
+        double diff[4], acc[4] = {0, 0, 0, 0};
+        for (int j = 0; j < n; ++j) {
+            double r2 = pair_r2(P, d, pos + (long)i * d, pos + (long)j * d, eps2_py, diff);
+            double q;
+            if (!grid) {
+                int Qd; q = hook_simple(mode, P, r2, &Qd);
+            } else if (degenerate) {
+                q = clamp_min(r2, scalar_as(P, min_val));
+                if (d2bins) d2bins[(long)(i - i0) * n + j] = -1;
+            } else {
+                double lt = gqs_log(P, r2, min_val);
+                double k = gqs_bin(P, lt, lmin, lmax, L);
+                if (d2bins) d2bins[(long)(i - i0) * n + j] = isnan(k) ? -2 : (int32_t)k;
+                q = gqs_value(P, k, lmin, lmax, L, min_val);
+            }
+            double p = rnd(Q, pow(q, 1.5));
+            double w = rnd(Q, rnd(Q, 1.0 / p) * Gs);
+            w = rnd(W, w * mass[j]);
+            w = rnd(W2, w * ((i == j) ? 0.0 : 1.0));
+            for (int k = 0; k < d; ++k) acc[k] += rnd(A, w * diff[k]);
+        }
+        for (int k = 0; k < d; ++k) acc_out[(long)(i - i0) * d + k] = rnd(A, acc[k]);
+    }
+    return A;
+}
+
 /* result dtype of _compute_accelerations without running it */
 int nbo_acc_dtype(int P, int M, int mode)
 {

@@ -43,6 +43,9 @@ def lib():
         L.nbo_accelerations.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, C.c_int,
                                         C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
                                         dp, dp, ip, ip, dp]
+        L.nbo_accelerations_rows.restype = C.c_int
+        L.nbo_accelerations_rows.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, C.c_int,
+                                             C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, ip]
         L.nbo_acc_dtype.restype = C.c_int
         L.nbo_acc_dtype.argtypes = [C.c_int, C.c_int, C.c_int]
         L.nbo_axpy.restype = C.c_int
@@ -132,6 +135,20 @@ def accelerations(pos, mass, mode, G=0.001, softening=0.1, levels=0, j_range=Non
         return acc, dict(lmin=dbg[0], lmax=dbg[1], fmin=dbg[2], fmax=dbg[3], d2bins=d2b, fbins=fb,
                          acc_prequant=from_f64(pre, A), acc_code=A)
     return acc
+
+
+def accelerations_rows(pos, mass, mode, i0, i1, G=0.001, softening=0.1, levels=0, bins=False):
+    """Rows [i0, i1) of `accelerations` (no force quantisation) at sizes where all N^2 pairs are too slow; the
+    grid's global lmin / lmax still come from all pairs.  Returns acc rows, dict(lmin, lmax[, d2bins])."""
+    pc, mc = dtype_code(pos), dtype_code(mass)
+    n, d = pos.shape
+    p64, m64 = as_f64(pos), as_f64(mass)
+    out = np.empty((i1 - i0, d), np.float64)
+    dbg = np.zeros(4, np.float64)
+    d2b = np.full((i1 - i0, n), -9, np.int32) if bins else None
+    A = lib().nbo_accelerations_rows(n, d, pc, _dp(p64), mc, _dp(m64), mode_code(mode), levels, float(G),
+                                     float(softening) ** 2, int(i0), int(i1), _dp(out), _dp(dbg), _ip(d2b))
+    return from_f64(out, A), dict(lmin=dbg[0], lmax=dbg[1], d2bins=d2b)
 
 
 def grid_quantize_safe(t, levels, min_val=0.01, bins=False):

@@ -28,6 +28,10 @@ What is captured:
   G10 tensor-level hooks on awkward inputs (0, negative, 1e30, inf, NaN, 2-3 levels, 1-D / 3-D / single element).
   G11 galaxy generators with non-default parameters.
   G12 main.py's metric flow (collect_metrics in a run() callback, compare_rotation_curves).
+  G13 quant-bin assignments AT SCALE from the reference itself: N = 4096 (D = 2, disk galaxy) and N = 2048 (D = 3),
+      INT8 / INT4 / CUSTOM(64): lmin, lmax, CRC-32 of every row of the int16 bin matrix, bin histogram, three full
+      rows, force-grid bounds and force bins, accelerations.
+  G14 state hash: reproducibility.hash_tensor_state of the reference on golden states (fp32 / fp64 / fp16).
   G7  half-typed state (float16 / bfloat16 tensors) through the cast modes and FLOAT64: energies before
       and after the promotion, state after three steps.
 
@@ -586,7 +590,61 @@ def g12():
     np.savez_compressed(os.path.join(OUT, "g12_metric_flow.npz"), **out)
 
 
+def g13():
+    """Bin assignments at sizes where tiles, pruning and the table-free pair path are all in play."""
+    import zlib
+    cases = []
+    torch.manual_seed(1313)
+    p2, v2, m2 = ref_galaxy.create_disk_galaxy(num_stars=4096, device=torch.device("cpu"))
+    cases.append(("n4096_d2", p2.float(), v2.float(), m2.float(), 0.1))
+    g = torch.Generator().manual_seed(1314)
+    p3 = torch.cat([p2[:2048], 0.4 * torch.randn(2048, 1, generator=g)], 1).float()
+    v3 = torch.cat([v2[:2048], torch.zeros(2048, 1)], 1).float()
+    m3 = (0.5 + torch.rand(2048, generator=g)).float()
+    cases.append(("n2048_d3", p3, v3, m3, 0.05))            # softening^2 below the grid floor 0.01: clamp active
+    for name, pos, vel, mass, eps in cases:
+        n = pos.shape[0]
+        out = dict(pos=npy(pos), vel=npy(vel), mass=npy(mass), eps=eps, G=0.001, dt=0.01)
+        for mode in (PrecisionMode.INT8_SIM, PrecisionMode.INT4_SIM, PrecisionMode.CUSTOM):
+            with Spy() as spy:
+                sim = ref_sim.GalaxySimulation(pos.clone(), vel.clone(), mass.clone(), precision_mode=mode, G=0.001,
+                                               softening=eps, dt=0.01)
+            tag = mode.value
+            tin, lv, mv, tout = spy.safe[0]
+            k, lmin, lmax = safe_bins(tin, lv, mv, tout)
+            k16 = np.ascontiguousarray(k.astype("<i2"))
+            out[f"{tag}/lmin"], out[f"{tag}/lmax"] = lmin, lmax
+            out[f"{tag}/row_crc"] = np.array([zlib.crc32(k16[i].tobytes()) for i in range(n)], np.uint32)
+            out[f"{tag}/hist"] = np.bincount(k16.ravel(), minlength=lv).astype(np.int64)
+            for r in (0, n // 2, n - 1):
+                out[f"{tag}/row{r}"] = k16[r]
+            out[f"{tag}/acc0"] = npy(sim.accelerations)
+            if spy.lin:
+                fin, flv, fout = spy.lin[0]
+                fk, fmin, fmax = lin_bins(fin, flv, fout)
+                out[f"{tag}/fbins"] = fk.astype(np.int16)
+                out[f"{tag}/fmin"], out[f"{tag}/fmax"] = fmin, fmax
+        np.savez_compressed(os.path.join(OUT, f"g13_bins_{name}.npz"), **out)
+        print("G13", name)
+
+
+def g14():
+    """The reference's own state hash (reproducibility.py:227-232) on golden states."""
+    import reproducibility as ref_repro
+    g2_ = np.load(os.path.join(OUT, "g2_config1_n1024.npz"))
+    pos, vel = torch.from_numpy(g2_["pos"]), torch.from_numpy(g2_["vel"])
+    out = {
+        "float32": ref_repro.hash_tensor_state(pos, vel),
+        "float64": ref_repro.hash_tensor_state(pos.double(), vel.double()),
+        "float16": ref_repro.hash_tensor_state(pos.half(), vel.half()),
+        "float64_tick200": ref_repro.hash_tensor_state(torch.from_numpy(g2_["float64/pos200"]),
+                                                       torch.from_numpy(g2_["float64/vel200"])),
+    }
+    json.dump(out, open(os.path.join(OUT, "g14_state_hash.json"), "w"), indent=1)
+    print("G14", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()
