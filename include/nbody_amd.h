@@ -160,6 +160,31 @@ int nb_grid_quantize(int device, const void *in, void *out, int64_t count, int d
 int nb_grid_quantize_safe(int device, const void *in, void *out, int64_t count, int dtype,
                           int levels, double min_val, int on_device);
 
+/* Stream of the calling thread for the handle-less entry points on `device` (the four hooks above and
+ * nb_metrics_tensors): they queue their kernels there and, for device-resident buffers, return without waiting --
+ * ordered with the caller's own device work like any other stream operation.  enable = 0 restores the default
+ * (NULL stream, blocking).  Thread-local; no device allocation per call (a per-device scratch is cached). */
+int nb_set_hook_stream(int device, void *hip_stream, int enable);
+
+/* ---- diagnostics --------------------------------------------------------------------- */
+
+/* metrics.py:25-156 on the handle's CURRENT state, on the device (no sort: an all-pairs ranking sweep gives the
+ * order statistic and the enclosed masses):
+ *   compute_rotation_curve  -> curve_mean[num_bins] (NaN for empty bins), curve_count[num_bins]
+ *   compute_galaxy_radius   -> scalars[1] = sorted(r)[min(int(n * percentile / 100), n - 1)]
+ *   compute_bound_fraction  -> scalars[2]        compute_velocity_dispersion -> scalars[3]
+ *   scalars[0] = radii.max(), scalars[4] = the max_radius the bin edges were built from.
+ * edges: host, num_bins + 1 float32 (what torch.linspace(0, max_radius, num_bins + 1) returns), or NULL to have
+ * them built here from max_radius (< 0: radii.max()).  radius_only != 0: only scalars[0] (first phase of a caller
+ * that builds the edges itself).  Any output pointer may be NULL. */
+int nb_metrics(nb_sim *s, int32_t num_bins, const float *edges, double max_radius, double percentile,
+               int32_t radius_only, double *curve_mean, int64_t *curve_count, double scalars[5]);
+/* The same on caller tensors (n x dim positions / velocities, n masses; NB_F32 or NB_F64; host or device). */
+int nb_metrics_tensors(int device, const void *pos, const void *vel, const void *mass, int32_t n, int32_t dim,
+                       int dtype, int on_device, double G, int32_t num_bins, const float *edges, double max_radius,
+                       double percentile, int32_t radius_only, double *curve_mean, int64_t *curve_count,
+                       double scalars[5]);
+
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------------------------------- */
 
 /* Partition: every rank holds the full O(N) state.  The pair work is split by

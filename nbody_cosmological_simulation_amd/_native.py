@@ -28,7 +28,7 @@ EXPORTS = [
     "nb_set_accelerations", "nb_compute_accelerations", "nb_step", "nb_kick_drift", "nb_kick",
     "nb_energy", "nb_quant_debug", "nb_quant_bins_rows", "nb_quantize_distance_squared", "nb_quantize_force",
     "nb_grid_quantize", "nb_grid_quantize_safe", "nb_comm_unique_id", "nb_comm_init", "nb_comm_ready",
-    "nb_comm_shutdown", "nb_plan_debug",
+    "nb_comm_shutdown", "nb_plan_debug", "nb_set_hook_stream", "nb_metrics", "nb_metrics_tensors",
     "nb_kernel_time", "nb_force_kernel_name", "nb_synchronize", "nb_device_count", "nb_abi_version", "nb_last_error",
 ]
 
@@ -84,6 +84,10 @@ def lib():
         "nb_grid_quantize_safe": ([C.c_int, vp, vp, i64, C.c_int, C.c_int, dbl, C.c_int], C.c_int),
         "nb_comm_unique_id": ([vp, pi32], C.c_int),
         "nb_comm_init": ([vp, vp, i32], C.c_int),
+        "nb_set_hook_stream": ([C.c_int, vp, C.c_int], C.c_int),
+        "nb_metrics": ([vp, i32, vp, dbl, dbl, i32, pdbl, C.POINTER(C.c_int64), pdbl], C.c_int),
+        "nb_metrics_tensors": ([C.c_int, vp, vp, vp, i32, i32, C.c_int, C.c_int, dbl, i32, vp, dbl, dbl, i32, pdbl,
+                                C.POINTER(C.c_int64), pdbl], C.c_int),
         "nb_comm_ready": ([], C.c_int),
         "nb_comm_shutdown": ([], C.c_int),
         "nb_plan_debug": ([C.POINTER(NbConfig), i32, i32, i32, pi32, pi32, i64, pi32, pi32, pi32, pi32, pi32], C.c_int),

@@ -650,7 +650,7 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
                             const float sq = __fmul_rn(df, df);
                             d2 = (k == 0) ? sq : __fadd_rn(d2, sq);
                         }
-                        const float dist = __fsqrt_rn(__fadd_rn(d2, eps2_f));
+                        const float dist = __builtin_sqrtf(__fadd_rn(d2, eps2_f));
                         term = (double)__fdiv_rn(mass_prod_f32((float)mi[ri], (float)mj[rj], mass_dt), dist);
                     } else {
                         double q = eps2;

@@ -177,3 +177,22 @@ hipError_t nb_launch_grid_quantize(const void *in, void *out, int is_f64, int64_
                                    const double *mn_mx, hipStream_t st);
 hipError_t nb_launch_grid_quantize_safe(const void *in, void *out, int is_f64, int64_t count, int levels,
                                         double min_val, const double *mn_mx, hipStream_t st);
+
+// ---- diagnostics (nb_metrics.hip; reference metrics.py:25-156) ------------------------------------------------
+struct NbMetricsArgs {
+    const void *pos, *vel, *mass;   // device, storage type S (float or double)
+    int n, dim;
+    int storage_f64;                // S
+    int arith_f64;                  // A: the tensors' logical dtype (per-particle arithmetic follows torch in A)
+    int num_bins;                   // rotation-curve bins (<= 255)
+    const float *edges;             // device, num_bins + 1 float32 bin edges, or null: linspace(0, max_radius) restated
+    double max_radius;              // < 0: radii.max()
+    int kth;                        // order statistic of the radii to report (min(int(N p / 100), N - 1))
+    double G;
+    int radius_only;                // 1: only out[0] = radii.max() (first phase of a caller that builds the edges itself)
+    void *scratch;                  // nb_metrics_scratch_bytes(n, num_bins)
+    double *out;                    // device, 5 + 2 num_bins doubles: max r, r_kth, bound count, dispersion, means[nb],
+                                    // counts[nb], max_radius used
+};
+size_t nb_metrics_scratch_bytes(int n, int num_bins);
+hipError_t nb_launch_metrics(const NbMetricsArgs &a, hipStream_t st);

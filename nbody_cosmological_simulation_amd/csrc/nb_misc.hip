@@ -413,7 +413,7 @@ potential_kernel(const T *__restrict__ pos, const T *__restrict__ mass, ForceGeo
                     d2 = (k == 0) ? sq : __fadd_rn(d2, sq);
                 }
                 d2 = round_hp<HP>(d2);
-                const float dist = round_hp<HP>(__fsqrt_rn(round_hp<HP>(__fadd_rn(d2, eps2_f))));
+                const float dist = round_hp<HP>(__builtin_sqrtf(round_hp<HP>(__fadd_rn(d2, eps2_f))));
                 term = (double)round_hp<HP>(__fdiv_rn(round_hp<HP>(nbdev::mass_prod_f32((float)mi, (float)sj[D][jj], mass_dt)), dist));
             } else {
                 double q = eps2;

@@ -1,15 +1,21 @@
 """Per-snapshot diagnostics -- same surface as the reference's metrics.py.
 
-Reference: metrics.py:12-227 (formulas restated in SURVEY.md Appendix C).  These are O(N log N)
-read-only consumers of `sim.positions / velocities / masses` evaluated a few times per run
-(every 100 ticks in main.py:161-167); they are NOT part of the accelerated path and run as
-plain host-side tensor code on whatever device the state tensors live on.  The O(N^2) energies
-they call (`get_kinetic_energy`, `get_potential_energy`) are the native kernels.
+Reference: metrics.py:12-227 (formulas restated in SURVEY.md Appendix C).  The four diagnostics run as HIP kernels
+behind the C-ABI (`nb_metrics` on a simulation's device-resident state, `nb_metrics_tensors` on caller tensors;
+csrc/nb_metrics.hip): radii, tangential speeds, the rotation-curve bins, the r-percentile order statistic, the
+enclosed masses behind the escape test and the dispersion never leave the device, and nothing is sorted.  The only
+host-side arithmetic kept is what the reference also does on the host: the 21 float32 bin edges come from
+`torch.linspace` itself, so bin membership is decided against bit-identical edges.  No torch fallback: without the
+HIP library these functions raise.
 """
+import ctypes as C
 from dataclasses import dataclass, field
 
 import numpy as np
 import torch
+
+from . import _native as N
+from .quantization import _TORCH_TO_NB, _hip_device_for, hook_stream
 
 
 @dataclass
@@ -25,70 +31,100 @@ class SimulationMetrics:
     rotation_curves: list = field(default_factory=list)
 
 
-def _radii(positions):
-    return torch.sqrt((positions ** 2).sum(dim=-1))
+def _edges(max_radius: float, num_bins: int):
+    """The reference's bin edges: torch.linspace(0, max_radius, num_bins + 1) (float32), as a host array."""
+    return np.ascontiguousarray(torch.linspace(0, max_radius, num_bins + 1).numpy(), dtype=np.float32)
+
+
+def _prep(t: torch.Tensor, dtype):
+    t = t.detach()
+    if t.dtype != dtype:
+        t = t.to(dtype)                 # mixed / half-typed tensors: evaluated in float32 (fp64 if any is fp64)
+    return t.contiguous()
+
+
+def native_metrics(positions, velocities, masses=None, G: float = 0.001, num_bins: int = 20,
+                   max_radius: float = None, percentile: float = 90, simulation=None) -> dict:
+    """All four diagnostics in one native evaluation.  `simulation`: use that engine's device-resident state
+    (`nb_metrics`) instead of the tensors (`nb_metrics_tensors`)."""
+    L = N.lib()
+    mean = (C.c_double * max(num_bins, 1))()
+    count = (C.c_int64 * max(num_bins, 1))()
+    sc = (C.c_double * 5)()
+
+    def call(edges, mr, radius_only):
+        ep = None if edges is None else edges.ctypes.data_as(C.c_void_p)
+        if simulation is not None:
+            N.check(L.nb_metrics(simulation._handle, num_bins, ep, mr, float(percentile), int(radius_only), mean, count, sc))
+            return
+        n, d = pos.shape
+        with hook_stream(pos):
+            N.check(L.nb_metrics_tensors(_hip_device_for(pos), C.c_void_p(pos.data_ptr()), C.c_void_p(vel.data_ptr()),
+                                         C.c_void_p(mas.data_ptr()), n, d, _TORCH_TO_NB[pos.dtype],
+                                         int(pos.device.type == "cuda"), float(G), num_bins, ep, mr, float(percentile),
+                                         int(radius_only), mean, count, sc))
+
+    if simulation is None:
+        dt = torch.float64 if torch.float64 in (positions.dtype, velocities.dtype) else torch.float32
+        pos, vel = _prep(positions, dt), _prep(velocities, dt).to(positions.device)
+        mas = _prep(masses if masses is not None else torch.ones(pos.shape[0], dtype=dt, device=pos.device), dt).to(pos.device)
+        if pos.shape[0] == 0:
+            raise RuntimeError("metrics of an empty galaxy are undefined (max() of an empty tensor upstream)")
+    if max_radius is None:
+        call(None, -1.0, True)                    # radii.max() from the device
+        max_radius = sc[0]
+    edges = _edges(max_radius, num_bins)
+    call(edges, float(max_radius), False)
+    return {"edges": edges, "mean": np.array(mean[:num_bins], np.float64), "count": [int(c) for c in count[:num_bins]],
+            "max_radius": float(max_radius), "r_percentile": sc[1], "bound_fraction": sc[2], "dispersion": sc[3]}
 
 
 def compute_rotation_curve(positions: torch.Tensor, velocities: torch.Tensor, num_bins: int = 20,
                            max_radius: float = None) -> dict:
     """Mean tangential speed in `num_bins` radial bins (reference metrics.py:25-78).
 
-    Bin i holds edge_i <= r < edge_{i+1}; empty bins give NaN; columns 0,1 define the plane."""
-    radii = _radii(positions)
-    if max_radius is None:
-        max_radius = radii.max().item()
-    v_tan = torch.abs(positions[:, 0] * velocities[:, 1] - positions[:, 1] * velocities[:, 0]) / radii.clamp(min=0.1)
-    edges = torch.linspace(0, max_radius, num_bins + 1, device=positions.device)
-    centres = (edges[:-1] + edges[1:]) / 2
-    # membership of bin i is edge_i <= r < edge_{i+1} exactly as upstream's masks (r == max_radius falls out of
-    # the last bin); all bins in one pass and one device-to-host transfer instead of two per bin.  Sums go
-    # through a one-hot matrix product: deterministic (no atomics), accumulated in fp64.
-    member = (radii.unsqueeze(1) >= edges[:-1].unsqueeze(0)) & (radii.unsqueeze(1) < edges[1:].unsqueeze(0))
-    onehot = member.to(torch.float64)
-    counts_t = onehot.sum(dim=0)
-    sums = onehot.t() @ v_tan.to(torch.float64)
-    means_t = (sums / counts_t).to(v_tan.dtype)           # 0 / 0 = NaN for empty bins, like upstream
-    stacked = torch.stack([means_t.to(torch.float64), counts_t]).cpu().numpy()
-    return {"radii": centres.cpu().numpy(), "velocities": stacked[0].astype(np.float64),
-            "num_stars_per_bin": [int(c) for c in stacked[1]]}
+    Bin i holds edge_i <= r < edge_{i+1} (the farthest star falls out of the last bin); empty bins give NaN; a star
+    with a non-finite radius belongs to no bin, a non-finite speed only affects its own bin; columns 0,1 define the
+    plane."""
+    m = native_metrics(positions, velocities, None, num_bins=num_bins, max_radius=max_radius)
+    e = torch.from_numpy(m["edges"])
+    return {"radii": ((e[:-1] + e[1:]) / 2).numpy(), "velocities": m["mean"], "num_stars_per_bin": m["count"]}
 
 
 def compute_galaxy_radius(positions: torch.Tensor, percentile: float = 90) -> float:
     """Radius containing `percentile` % of the stars (reference metrics.py:81-95)."""
-    radii = _radii(positions)
-    idx = int(len(radii) * percentile / 100)
-    return torch.sort(radii)[0][min(idx, len(radii) - 1)].item()
+    return native_metrics(positions, torch.zeros_like(positions), None, num_bins=0, max_radius=1.0,
+                          percentile=percentile)["r_percentile"]
 
 
 def compute_bound_fraction(positions: torch.Tensor, velocities: torch.Tensor, masses: torch.Tensor,
                            G: float = 0.001) -> float:
     """Fraction of stars slower than the local escape speed (reference metrics.py:98-145)."""
-    total_mass = masses.sum()
-    com = (positions * masses.unsqueeze(-1)).sum(dim=0) / total_mass
-    r_com = torch.sqrt(((positions - com) ** 2).sum(dim=-1))
-    order = torch.argsort(r_com)
-    enclosed = torch.cumsum(masses[order], dim=0)[torch.argsort(order)]
-    v_esc = torch.sqrt(2 * G * enclosed / r_com.clamp(min=0.1))
-    v_mag = torch.sqrt((velocities ** 2).sum(dim=-1))
-    return (v_mag < v_esc).float().mean().item()
+    return native_metrics(positions, velocities, masses, G=G, num_bins=0, max_radius=1.0)["bound_fraction"]
 
 
 def compute_velocity_dispersion(velocities: torch.Tensor) -> float:
     """Unbiased standard deviation of |v| (reference metrics.py:148-156)."""
-    return torch.sqrt((velocities ** 2).sum(dim=-1)).std().item()
+    return native_metrics(torch.zeros_like(velocities), velocities, None, num_bins=0, max_radius=1.0)["dispersion"]
 
 
 def collect_metrics(simulation, tick: int, metrics: SimulationMetrics):
-    """Append every diagnostic for the current state (reference metrics.py:159-179)."""
-    pos, vel, masses = simulation.positions, simulation.velocities, simulation.masses
+    """Append every diagnostic for the current state (reference metrics.py:159-179): energies and all four
+    diagnostics from the engine's device-resident state, one native evaluation, no state download."""
     metrics.ticks.append(tick)
     metrics.kinetic_energy.append(simulation.get_kinetic_energy())
     metrics.potential_energy.append(simulation.get_potential_energy())
     metrics.total_energy.append(simulation.get_total_energy())
-    metrics.galaxy_radius_90.append(compute_galaxy_radius(pos, 90))
-    metrics.bound_fraction.append(compute_bound_fraction(pos, vel, masses, simulation.G))
-    metrics.velocity_dispersion.append(compute_velocity_dispersion(vel))
-    metrics.rotation_curves.append(compute_rotation_curve(pos, vel))
+    if hasattr(simulation, "_native_metrics_ready") and simulation._native_metrics_ready():
+        m = native_metrics(None, None, None, simulation=simulation)
+    else:                       # another object with the same attributes (or an empty galaxy): through the tensors
+        m = native_metrics(simulation.positions, simulation.velocities, simulation.masses, G=simulation.G)
+    e = torch.from_numpy(m["edges"])
+    metrics.galaxy_radius_90.append(m["r_percentile"])
+    metrics.bound_fraction.append(m["bound_fraction"])
+    metrics.velocity_dispersion.append(m["dispersion"])
+    metrics.rotation_curves.append({"radii": ((e[:-1] + e[1:]) / 2).numpy(), "velocities": m["mean"],
+                                    "num_stars_per_bin": m["count"]})
 
 
 def compare_rotation_curves(curve1: dict, curve2: dict, label1: str = "Baseline", label2: str = "Quantized") -> dict:

@@ -51,11 +51,33 @@ def _run_hook(t: torch.Tensor, out_dtype, call):
     out = torch.empty(src.shape, dtype=out_dtype, device=src.device)
     if src.numel() == 0:
         return out
-    if on_device:
-        torch.cuda.current_stream(src.device).synchronize()
-    N.check(call(_hip_device_for(src), C.c_void_p(src.data_ptr()), C.c_void_p(out.data_ptr()),
-                 src.numel(), _TORCH_TO_NB[src.dtype], int(on_device)))
+    # device tensors: the kernels are queued on torch's current stream (no synchronisation, no allocation: the
+    # library keeps a per-device scratch); host tensors: staged through that scratch, the call waits for the copy back
+    with hook_stream(src):
+        N.check(call(_hip_device_for(src), C.c_void_p(src.data_ptr()), C.c_void_p(out.data_ptr()),
+                     src.numel(), _TORCH_TO_NB[src.dtype], int(on_device)))
     return out
+
+
+class hook_stream:
+    """Tell the library which stream the calling thread's device work runs on (nb_set_hook_stream) for the duration
+    of a handle-less call: torch's current stream of the tensor's device, or the default for host tensors."""
+
+    def __init__(self, tensor):
+        self.dev = _hip_device_for(tensor)
+        self.cuda = tensor.device.type == "cuda"
+        self.tensor = tensor
+
+    def __enter__(self):
+        if self.cuda:
+            st = torch.cuda.current_stream(self.tensor.device).cuda_stream
+            N.check(N.lib().nb_set_hook_stream(self.dev, C.c_void_p(st), 1))
+        return self
+
+    def __exit__(self, *exc):
+        if self.cuda:
+            N.lib().nb_set_hook_stream(self.dev, None, 0)
+        return False
 
 
 def _grid_quantize(tensor: torch.Tensor, levels: int) -> torch.Tensor:

@@ -151,6 +151,12 @@ class GalaxySimulation:
         t = tensor.detach()
         if t.dtype not in _TORCH_TO_NB:
             raise TypeError(f"{name}: unsupported dtype {t.dtype}")
+        # the native side copies exactly N (x D) elements from this pointer: a rebound tensor of another shape
+        # (sim.positions = sim.positions[:100], a wrong-D override result) must fail here, like the broadcast
+        # error it would raise upstream, not read out of bounds
+        want = (self.num_stars,) if name == "masses" else (self.num_stars, self._cfg_dim)
+        if tuple(t.shape) != want:
+            raise ValueError(f"{name} must have shape {want}, got {tuple(t.shape)}")
         t = t.contiguous()
         on_device = t.device.type == "cuda"
         if on_device:
@@ -223,6 +229,13 @@ class GalaxySimulation:
         self._serial += 1
         for name in names:
             self._cache.pop(name, None)
+
+    def _native_metrics_ready(self) -> bool:
+        """metrics.collect_metrics: push pending edits down so the diagnostics can run on the device state."""
+        if self._empty:
+            return False
+        self._flush(("positions", "velocities", "masses"))
+        return True
 
     def _overridden(self):
         return type(self)._compute_accelerations is not GalaxySimulation._compute_accelerations

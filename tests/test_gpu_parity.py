@@ -1359,3 +1359,97 @@ def test_config2_energy_drift_vs_oracle_200_ticks(nb):
     size = np.abs(p).max()
     assert np.abs(sim.positions.numpy() - p).max() / size < 1e-10
     assert np.abs(sim.velocities.numpy() - v).max() / np.abs(v).max() < 1e-9
+
+
+# --------------------------------------------------------------------------- native diagnostics (nb_metrics)
+def test_native_metrics_vs_reference_goldens(nb):
+    """The HIP diagnostics (nb_metrics_tensors through metrics.py) on the reference's own galaxies (g6): rotation
+    curve (20 bins / 7 bins with a fixed max radius), r90 / r50, bound fraction, velocity dispersion."""
+    from nbody_cosmological_simulation_amd import metrics
+    g = load_golden("g6_galaxy_metrics.npz")
+    for name in ("disk", "test", "halo"):
+        for dev in ("cpu", "cuda"):
+            p, v, m = (torch.from_numpy(g[f"{name}/{k}"]).to(dev) for k in ("pos", "vel", "mass"))
+            rc = metrics.compute_rotation_curve(p, v)
+            assert np.allclose(rc["radii"], g[f"{name}/rc_r"], rtol=1e-6)
+            assert list(rc["num_stars_per_bin"]) == list(g[f"{name}/rc_n"])
+            assert np.allclose(rc["velocities"], g[f"{name}/rc_v"], rtol=2e-6, equal_nan=True)
+            rc7 = metrics.compute_rotation_curve(p, v, num_bins=7, max_radius=12.5)
+            assert np.allclose(rc7["velocities"], g[f"{name}/rc7_v"], rtol=2e-6, equal_nan=True)
+            assert abs(metrics.compute_galaxy_radius(p, 90) - float(g[f"{name}/r90"])) <= 1e-6 * float(g[f"{name}/r90"])
+            assert abs(metrics.compute_galaxy_radius(p, 50) - float(g[f"{name}/r50"])) <= 1e-6 * float(g[f"{name}/r50"])
+            assert abs(metrics.compute_bound_fraction(p, v, m, 0.001) - float(g[f"{name}/bound"])) <= 1e-6
+            assert abs(metrics.compute_velocity_dispersion(v) - float(g[f"{name}/disp"])) <= 2e-6 * float(g[f"{name}/disp"])
+
+
+@pytest.mark.parametrize("n,dtype", [(65536, "float32"), (65536, "float64"), (3001, "float32")])
+def test_native_metrics_vs_oracle_at_scale(nb, n, dtype):
+    """nb_metrics on an engine's device-resident state (collect_metrics' path) and nb_metrics_tensors against the
+    numpy restatement at config 3's size: bin counts identical, means / r90 / dispersion to rounding, bound
+    fraction exact for unit masses; unequal masses and non-finite stars (NaN position: no bin; infinite speed:
+    its own bin only)."""
+    from oracle import metrics_oracle as MO
+    from nbody_cosmological_simulation_amd import galaxy, metrics
+    pos, vel, mass = galaxy.create_disk_galaxy(n, seed=9, device="cpu")
+    npdt = np.float64 if dtype == "float64" else np.float32
+    if dtype == "float64":
+        pos, vel, mass = pos.double(), vel.double(), mass.double()
+    mode = nb.PrecisionMode.FLOAT64 if dtype == "float64" else nb.PrecisionMode.FLOAT32
+    sim = nb.GalaxySimulation(pos, vel, mass, precision_mode=mode)
+    sim.run(2)
+    m = metrics.SimulationMetrics()
+    metrics.collect_metrics(sim, sim.tick, m)
+    p, v, ms = sim.positions.numpy().astype(npdt), sim.velocities.numpy().astype(npdt), sim.masses.numpy().astype(npdt)
+    edges = torch.linspace(0, float(MO.radii(p).max()), 21).numpy()
+    ref = MO.rotation_curve(p, v, edges=edges)
+    got = m.rotation_curves[0]
+    assert got["num_stars_per_bin"] == ref["num_stars_per_bin"]
+    assert np.allclose(got["velocities"], ref["velocities"], rtol=2e-6, equal_nan=True)
+    assert m.galaxy_radius_90[0] == MO.galaxy_radius(p, 90)                 # an order statistic: exact
+    assert m.bound_fraction[0] == MO.bound_fraction(p, v, ms, sim.G)        # unit masses: exact enclosed masses
+    assert abs(m.velocity_dispersion[0] - MO.velocity_dispersion(v)) <= 2e-6 * MO.velocity_dispersion(v)
+    # tensor-level entry, unequal masses, awkward stars
+    rng = np.random.default_rng(n)
+    ms2 = (0.5 + rng.random(n)).astype(npdt)
+    bf = metrics.compute_bound_fraction(torch.from_numpy(p), torch.from_numpy(v), torch.from_numpy(ms2), 0.001)
+    assert abs(bf - MO.bound_fraction(p, v, ms2, 0.001)) <= 3.0 / n       # fp32 cumsum order: a borderline star or two
+    v2, p2 = v.copy(), p.copy()
+    v2[5, 1] = np.inf
+    p2[17, 0] = np.nan
+    rc = metrics.compute_rotation_curve(torch.from_numpy(p2).cuda(), torch.from_numpy(v2).cuda(), num_bins=5, max_radius=10.0)
+    ref2 = MO.rotation_curve(p2, v2, num_bins=5, max_radius=10.0, edges=torch.linspace(0, 10.0, 6).numpy())
+    assert rc["num_stars_per_bin"] == ref2["num_stars_per_bin"]
+    assert np.allclose(rc["velocities"], ref2["velocities"], rtol=2e-6, equal_nan=True)
+    assert np.isinf(rc["velocities"]).sum() == 1
+
+
+def test_shape_checks_before_native_calls(nb):
+    """A rebound state tensor of another shape must raise before the native copy (which trusts N x D)."""
+    g = load_golden("g1_n64_d2_e0.1.npz")
+    sim = mk(nb, g, "float64")
+    sim.positions = sim.positions[:10]
+    with pytest.raises(ValueError):
+        sim.step()
+    sim = mk(nb, g, "float32")
+    sim.masses = torch.ones(65)
+    with pytest.raises(ValueError):
+        sim.get_potential_energy()
+
+
+def test_tensor_hooks_follow_the_callers_stream(nb):
+    """The handle-less hooks queue on torch's current stream and do not synchronise for device tensors: a hook
+    called under a side stream right after the producer kernel on that stream must see the producer's data."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs torch's HIP device")
+    from nbody_cosmological_simulation_amd import quantization as Q
+    side = torch.cuda.Stream()
+    x = torch.rand(1 << 20, device="cuda") * 50 + 0.02
+    with torch.cuda.stream(side):
+        y = x * 2.0                               # producer on the side stream
+        q = Q._grid_quantize_safe(y, 64)
+        z = q + 0.0                               # consumer on the side stream
+    side.synchronize()
+    ref = Q._grid_quantize_safe((x * 2.0).cpu(), 64)
+    assert torch.equal(z.cpu(), ref)
+    for _ in range(3):                            # repeated calls reuse the cached scratch
+        assert torch.equal(Q._grid_quantize_safe(x, 256).cpu(), Q._grid_quantize_safe(x.cpu(), 256))

@@ -467,3 +467,38 @@ def test_g14_state_hash_matches_reference():
     # bfloat16 (numpy has no such dtype; upstream's .numpy() raises there): hashed over the raw 16-bit patterns
     hb = checkpoint.state_hash(pos.bfloat16(), vel.bfloat16())
     assert len(hb) == 16 and hb != want["float16"]
+
+
+def test_metrics_oracle_vs_reference():
+    """oracle/metrics_oracle.py (the checker of the native nb_metrics kernels) on the reference's own galaxies (g6):
+    rotation curve (20 bins, and 7 bins with a fixed max radius), r90 / r50, bound fraction, velocity dispersion."""
+    from oracle import metrics_oracle as MO
+    g = load_golden("g6_galaxy_metrics.npz")
+    for name in ("disk", "test", "halo"):
+        p, v, m = (g[f"{name}/{k}"] for k in ("pos", "vel", "mass"))
+        rc = MO.rotation_curve(p, v)
+        assert np.allclose(rc["radii"], g[f"{name}/rc_r"], rtol=1e-6)
+        assert list(rc["num_stars_per_bin"]) == list(g[f"{name}/rc_n"])
+        assert np.allclose(rc["velocities"], g[f"{name}/rc_v"], rtol=2e-6, equal_nan=True)
+        rc7 = MO.rotation_curve(p, v, num_bins=7, max_radius=12.5)
+        assert np.allclose(rc7["velocities"], g[f"{name}/rc7_v"], rtol=2e-6, equal_nan=True)
+        assert abs(MO.galaxy_radius(p, 90) - float(g[f"{name}/r90"])) <= 1e-6 * float(g[f"{name}/r90"])
+        assert abs(MO.galaxy_radius(p, 50) - float(g[f"{name}/r50"])) <= 1e-6 * float(g[f"{name}/r50"])
+        assert abs(MO.bound_fraction(p, v, m, 0.001) - float(g[f"{name}/bound"])) <= 1e-6
+        assert abs(MO.velocity_dispersion(v) - float(g[f"{name}/disp"])) <= 2e-6 * float(g[f"{name}/disp"])
+
+
+def test_metrics_oracle_non_finite_stars():
+    """One star with a NaN position belongs to no bin and one with an infinite speed only spoils its own bin
+    (the reference's per-bin masked means, metrics.py:62-68) -- what blown-up INT4 runs produce."""
+    from oracle import metrics_oracle as MO
+    rng = np.random.default_rng(3)
+    p = (rng.standard_normal((500, 2)) * 3).astype(np.float32)
+    v = (rng.standard_normal((500, 2)) * 0.2).astype(np.float32)
+    v[7, 1] = np.inf
+    rc = MO.rotation_curve(p, v, num_bins=5, max_radius=10.0)
+    assert np.isinf(rc["velocities"]).sum() == 1 and np.isfinite(rc["velocities"]).sum() == 4
+    p[11, 0] = np.nan
+    rc2 = MO.rotation_curve(p, v, num_bins=5, max_radius=10.0)
+    assert sum(rc2["num_stars_per_bin"]) == sum(rc["num_stars_per_bin"]) - 1
+    assert np.isfinite(rc2["velocities"]).sum() == 4
