@@ -55,7 +55,7 @@ typedef struct nb_config {
     int32_t n;             /* num_stars                                                     */
     int32_t dim;           /* 2 or 3 (positions are (n, dim) row-major)                     */
     int32_t mode;          /* nb_mode                                                       */
-    int32_t levels;        /* CUSTOM grid levels, 2..4096 fused; 0 -> 64 (quantization.py:66) */
+    int32_t levels;        /* CUSTOM grid levels (>= 2; above 4096 on the generic per-pair path); 0 -> 64 (quantization.py:66) */
     double  G;             /* gravitational constant                                        */
     double  softening_sq;  /* softening**2 evaluated in Python double (simulation.py:59)    */
     double  dt;            /* time step                                                     */
@@ -70,6 +70,10 @@ typedef struct nb_config {
 #define NB_FLAG_NO_COMM       4   /* nranks > 1 without RCCL: nb_compute_accelerations leaves this rank's
                                      PARTIAL sums (no all-reduce, no force quantisation) for the caller
                                      to reduce; nb_step is refused.  Used by single-GPU shard tests.   */
+
+#define NB_FLAG_F64_STORAGE   16   /* at least one of positions / velocities / masses will be uploaded as fp64 although the
+                                     first upload may be fp32: keep the state in fp64 storage from the start (torch
+                                     promotes such a simulation to fp64 through the mass product / the first kick) */
 
 #define NB_FLAG_SHARD_TIMING   8   /* timing experiments on ONE GPU: compute only shard `rank` of `nranks`
                                      but run the collectives on a 1-rank communicator.  Results are

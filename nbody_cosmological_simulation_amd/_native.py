@@ -16,6 +16,7 @@ NB_FLAG_PROFILE = 1
 NB_FLAG_CUSTOM_FORCEQ = 2
 NB_FLAG_NO_COMM = 4
 NB_FLAG_SHARD_TIMING = 8
+NB_FLAG_F64_STORAGE = 16
 
 MODE_CODES = {
     "float64": 0, "float32": 1, "bfloat16": 2, "float16": 3,

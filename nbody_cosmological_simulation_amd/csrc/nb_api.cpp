@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -159,6 +160,8 @@ struct nb_sim {
         double *rowslab = nullptr;
         std::vector<int> chunk_work, chunk_tile;      // pipeline chunks (host side, see nb_plan.h)
     } sym;
+    void *gen_scalars = nullptr;         // generic (dtype-faithful) path: device scalars of one evaluation
+    bool last_generic = false;           // the last force evaluation ran on the generic path (no threshold tables)
     void *metrics_scratch = nullptr;     // nb_metrics work arrays (allocated on first use)
     size_t metrics_cap = 0;
     NbKnobs knobs;                       // environment knobs, read once in nb_create
@@ -393,6 +396,64 @@ int prof_end(nb_sim *s, int slot)
     return NB_OK;
 }
 
+// Which evaluations take the dtype-faithful generic kernel (nb_generic.hip): dtype chains no script of the
+// reference builds but its stock class accepts.
+bool use_generic(const nb_sim *s)
+{
+    const nb_config &c = s->cfg;
+    if (grid_mode(c.mode) && mode_levels(c) > NB_MAX_LUT) return true;       // fused grids beyond the table capacity
+    if (s->is_f64) {
+        if (c.mode == NB_FLOAT64) return false;
+        if (grid_mode(c.mode)) return true;                                  // grid over an fp64 (or fp64-stored) tensor
+        return s->logical[0] != NB_F64;      // cast mode before the promotion: fp32 / half positions beside fp64 tensors
+    }
+    return grid_mode(c.mode) && is_half(s->logical[0]);                      // grid over a half tensor
+}
+
+int force_eval_generic(nb_sim *s, bool do_kick, bool *defer_kick, bool *open_next)
+{
+    const nb_config &c = s->cfg;
+    const int64_t cnt = nd(s);
+    const bool no_comm = (c.flags & NB_FLAG_NO_COMM) != 0;
+    const bool multi = comm_active(s);
+    if (multi && !s->comm) return fail(NB_ERR_COMM, "nranks > 1 but nb_comm_init was not called");
+    const bool fq = force_quant_mode(c) && !(no_comm && c.nranks > 1);
+    const int L = mode_levels(c);
+    if (grid_mode(c.mode) && L < 2) return fail(NB_ERR_INVALID, "grid levels must be >= 2 (got %d)", L);
+    const int A = acc_logical_dtype(s);
+    if (!s->gen_scalars) HIPCHK(hipMalloc(&s->gen_scalars, nb_generic_scalars_bytes()));
+    if (grid_mode(c.mode))       // every rank scans all pairs itself: no collective for the grid bounds
+        HIPCHK(nb_launch_generic_r2max(s->pos, s->is_f64, c.n, c.dim, s->logical[0], c.softening_sq, s->gen_scalars, s->stream));
+    HIPCHK(nb_launch_generic_force(s->pos, s->mass, s->is_f64, s->partial, s->geom, c.dim, s->logical[0], s->logical[2], c.mode,
+                                   L, c.G, c.softening_sq, s->gen_scalars, s->acc, A, s->stream));
+    s->last_kernel = "generic_force_kernel";
+    s->last_generic = true;
+    if (multi)
+        NCCLCHK(g_rccl.AllReduce(s->acc, s->acc, (size_t)cnt, s->is_f64 ? ncclDouble : ncclFloat, ncclSum, s->comm, s->stream));
+    if (fq) {
+        // quantize_force on a tensor of dtype A (quantization.py:74-88): linear grid over its global min / max
+        const bool a64 = (A == NB_F64);
+        if (a64 == s->is_f64) {
+            HIPCHK(nb_launch_minmax_generic(s->acc, s->is_f64, cnt, 0, 0.0, s->scalars, s->scalars + 8, s->stream));
+            HIPCHK(nb_launch_grid_quantize(s->acc, s->acc, s->is_f64, cnt, L, s->scalars, s->stream));
+        } else {
+            // fp32-typed forces held in fp64 storage: quantise in fp32 through the staging buffer
+            HIPCHK(nb_launch_convert(s->acc, NB_F64, s->staging, NB_F32, cnt, s->stream));
+            HIPCHK(nb_launch_minmax_generic(s->staging, 0, cnt, 0, 0.0, s->scalars, s->scalars + 8, s->stream));
+            HIPCHK(nb_launch_grid_quantize(s->staging, s->staging, 0, cnt, L, s->scalars, s->stream));
+            HIPCHK(nb_launch_convert(s->staging, NB_F32, s->acc, NB_F64, cnt, s->stream));
+        }
+    }
+    if (open_next) *open_next = false;
+    if (do_kick) {
+        if (defer_kick) *defer_kick = true;
+        else HIPCHK(nb_launch_axpy(s->vel, s->acc, c.dt / 2, cnt, s->is_f64, s->stream));
+    }
+    s->logical[3] = A;
+    s->have_acc = true;
+    return NB_OK;
+}
+
 // one evaluation of simulation.py:74-118; optionally followed by the closing half kick (:141)
 // defer_kick: the caller will apply the closing half kick itself (fused into the next step's
 // opening launch) when this evaluation cannot fuse it into its reduction.
@@ -410,6 +471,8 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
     const bool multi = (c.nranks > 1 && !no_comm) || s->comm != nullptr;
     if (multi && !s->comm) return fail(NB_ERR_COMM, "nranks > 1 but nb_comm_init was not called");
     if (no_comm && c.nranks > 1 && do_kick) return fail(NB_ERR_INVALID, "NB_FLAG_NO_COMM handles cannot step");
+    if (use_generic(s)) return force_eval_generic(s, do_kick, defer_kick, open_next);
+    s->last_generic = false;
     int slot;
     bool used_sym = false, sym_uniform = false;
 
@@ -719,7 +782,7 @@ int nb_destroy(nb_sim *s)
                     (void *)s->scratch, (void *)s->scalars, (void *)s->fbins, (void *)s->sym.work,
                     (void *)s->sym.row_slot0, (void *)s->sym.row_nslots, (void *)s->sym.col_upto,
                     (void *)s->sym.packed, (void *)s->sym.packed_alt, (void *)s->sym.rowslab, (void *)s->sym.colslab,
-                    (void *)s->prune_cand, (void *)s->prune_rho, (void *)s->prune_state, s->metrics_scratch})
+                    (void *)s->prune_cand, (void *)s->prune_rho, (void *)s->prune_state, s->metrics_scratch, s->gen_scalars})
         if (p) (void)hipFree(p);
     if (s->prof_init)
         for (int i = 0; i < PROF_RING; ++i) { (void)hipEventDestroy(s->ev_start[i]); (void)hipEventDestroy(s->ev_stop[i]); }
@@ -746,14 +809,11 @@ int nb_set_state(nb_sim *s, const void *pos, const void *vel, const void *mass, 
     if (dtype < NB_F16 || dtype > NB_F64) return fail(NB_ERR_INVALID, "bad dtype %d", dtype);
     DeviceGuard guard(s->cfg.device);
     const int mode = s->cfg.mode;
-    if (is_half(dtype) && grid_mode(mode))
-        return fail(NB_ERR_UNSUPPORTED, "float16/bfloat16 state under a grid (INT8/INT4/CUSTOM) precision mode is "
-                                        "not implemented");
-    if (dtype == NB_F64 && grid_mode(mode))
-        return fail(NB_ERR_UNSUPPORTED, "fp64 state with a grid (INT8/INT4/CUSTOM) precision mode is not implemented");
-    const bool want_f64 = (mode == NB_FLOAT64) || dtype == NB_F64;
+    const bool want_f64 = (mode == NB_FLOAT64) || dtype == NB_F64 || (s->cfg.flags & NB_FLAG_F64_STORAGE);
     if (int rc = ensure_storage(s, s->have_storage ? s->is_f64 : want_f64)) return rc;
-    if (dtype == NB_F64 && !s->is_f64) return fail(NB_ERR_UNSUPPORTED, "cannot upload fp64 data into fp32 state");
+    if (dtype == NB_F64 && !s->is_f64)
+        return fail(NB_ERR_UNSUPPORTED, "cannot upload fp64 data into fp32 state storage: create the handle with "
+                                        "NB_FLAG_F64_STORAGE when any of positions / velocities / masses is fp64");
     if (pos) { if (int rc = upload(s, pos, dtype, on_device, s->pos, nd(s))) return rc; s->logical[0] = dtype; s->have_pos = true; }
     if (vel) { if (int rc = upload(s, vel, dtype, on_device, s->vel, nd(s))) return rc; s->logical[1] = dtype; s->have_vel = true; }
     if (mass) {
@@ -967,6 +1027,7 @@ int nb_quant_debug(nb_sim *s, double info[8], int16_t *d2bins, int16_t *fbins)
     if (!s) return fail(NB_ERR_INVALID, "null handle");
     if (!s->have_storage || s->is_f64 || !grid_mode(s->cfg.mode))
         return fail(NB_ERR_INVALID, "quant debug is only defined for the grid modes");
+    if (s->last_generic) return fail(NB_ERR_UNSUPPORTED, "quant debug: the last evaluation ran on the generic per-pair path (no tables)");
     DeviceGuard guard(s->cfg.device);
     GridTables h;
     double mnmx[2];
@@ -1011,9 +1072,13 @@ thread_local bool g_hook_stream_set[MAX_DEV];
 
 int check_device(int device)
 {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(NB_ERR_NO_DEVICE, "no HIP device available; this library has no CPU fallback");
+    static std::atomic<int> cached{-1};           // the device count does not change while the process lives
+    int ndev = cached.load();
+    if (ndev < 0) {
+        if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+        cached.store(ndev);
+    }
+    if (ndev == 0) return fail(NB_ERR_NO_DEVICE, "no HIP device available; this library has no CPU fallback");
     if (device < 0 || device >= ndev || device >= MAX_DEV) return fail(NB_ERR_NO_DEVICE, "device %d out of range", device);
     return NB_OK;
 }

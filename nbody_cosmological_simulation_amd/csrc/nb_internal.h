@@ -196,3 +196,12 @@ struct NbMetricsArgs {
 };
 size_t nb_metrics_scratch_bytes(int n, int num_bins);
 hipError_t nb_launch_metrics(const NbMetricsArgs &a, hipStream_t st);
+
+// ---- dtype-faithful generic force evaluation (nb_generic.hip) ---------------------------------------------------
+size_t nb_generic_scalars_bytes();
+hipError_t nb_launch_generic_r2max(const void *pos, int storage_f64, int n, int dim, int P, double eps2_py, void *sc,
+                                   hipStream_t st);
+hipError_t nb_launch_generic_force(const void *pos, const void *mass, int storage_f64, double *partial, const ForceGeom &geom,
+                                   int dim, int P /* positions' dtype */, int M /* masses' dtype */, int mode, int levels,
+                                   double G, double eps2_py, const void *sc, void *acc, int A /* result dtype */,
+                                   hipStream_t st);

@@ -139,6 +139,13 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
         if (ord[S] >= 0) { nch_of[S] = (T - 4 * S + cl - 1) / cl; items += nch_of[S]; }
     if (knobs.sym_split) {
         for (int S = 0; S < SR; ++S) split_of[S] = knobs.sym_split;
+    } else if (items <= 100) {
+        // Very small systems are bound by the LATENCY of one 64-step sweep (~4 us: a bpermute + a dependent VALU chain
+        // per step), not by throughput: a few dozen workgroups leave most of the chip idle.  Cutting every sweep into
+        // pieces shortens the critical path (measured fp64 N = 1024, 40 items: 12.1 / 9.2 / 8.0 / 9.1 us per step
+        // with 1 / 2 / 4 / 8 pieces; N = 2048, 144 items: no gain).
+        const int pieces = items < 24 ? 8 : (items <= 64 ? 4 : 2);
+        for (int S = 0; S < SR; ++S) split_of[S] = pieces;
     } else if (items > wg_slots / 2) {
         long long rem = items % wg_slots;
         // a single round of workgroups has nothing to hide a straggler behind: finer pieces there

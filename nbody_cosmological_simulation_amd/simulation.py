@@ -86,6 +86,8 @@ class GalaxySimulation:
             # sums of its source block (single-GPU shard tests / caller-side reduction)
             rank, world = int(shard[0]), int(shard[1])
             flags |= N.NB_FLAG_NO_COMM
+        if torch.float64 in (positions.dtype, velocities.dtype, masses.dtype):
+            flags |= N.NB_FLAG_F64_STORAGE     # torch promotes such a run to fp64 (mass product / first kick)
         if self.device.type == "cuda":
             dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
         else:

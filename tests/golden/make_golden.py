@@ -32,6 +32,8 @@ What is captured:
       INT8 / INT4 / CUSTOM(64): lmin, lmax, CRC-32 of every row of the int16 bin matrix, bin histogram, three full
       rows, force-grid bounds and force bins, accelerations.
   G14 state hash: reproducibility.hash_tensor_state of the reference on golden states (fp32 / fp64 / fp16).
+  G15 dtype combinations the stock class accepts beyond G1-G7: fp64 masses beside fp32 positions under every mode,
+      grid modes (INT8 / INT4 / CUSTOM) on fp64 state, grid modes on float16 / bfloat16 state.
   G7  half-typed state (float16 / bfloat16 tensors) through the cast modes and FLOAT64: energies before
       and after the promotion, state after three steps.
 
@@ -628,6 +630,64 @@ def g13():
         print("G13", name)
 
 
+def g15():
+    """Mixed / unusual dtype combinations through the stock class (quantization.py:58-69 is dtype-polymorphic,
+    simulation.py:105 promotes through the mass product)."""
+    pos, vel, mass = make_ics(193, 2, 15, True)
+    out = dict(pos=npy(pos), vel=npy(vel), mass=npy(mass), eps=0.1, G=0.001, dt=0.01)
+
+    def run(tag, p, v, m, mode):
+        try:
+            with Spy() as spy:
+                sim = ref_sim.GalaxySimulation(p.clone(), v.clone(), m.clone(), precision_mode=mode, G=0.001,
+                                               softening=0.1, dt=0.01, device=torch.device("cpu"))
+            out[f"{tag}/dtypes0"] = np.array([str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.masses.dtype),
+                                              str(sim.accelerations.dtype)])
+            out[f"{tag}/acc0"] = npy(sim.accelerations.double() if sim.accelerations.dtype != torch.float64 else sim.accelerations)
+            out[f"{tag}/e0"] = np.array([sim.get_kinetic_energy(), sim.get_potential_energy()])
+            if spy.safe:
+                tin, lv, mv, tout = spy.safe[0]
+                out[f"{tag}/r2_dtype"] = np.array(str(tin.dtype))
+                if tin.dtype in (torch.float32, torch.float64):
+                    k, lmin, lmax = safe_bins(tin, lv, mv, tout)
+                    if k is not None:
+                        out[f"{tag}/d2bins"] = k.astype(np.int16)
+                    out[f"{tag}/lmin"], out[f"{tag}/lmax"] = lmin, lmax
+                else:
+                    out[f"{tag}/q_out"] = npy(tout.double())
+            if spy.lin:
+                fin, flv, fout = spy.lin[0]
+                if fin.dtype in (torch.float32, torch.float64):
+                    fk, fmin, fmax = lin_bins(fin, flv, fout)
+                    if fk is not None:
+                        out[f"{tag}/fbins"] = fk.astype(np.int16)
+                    out[f"{tag}/fmin"], out[f"{tag}/fmax"] = fmin, fmax
+            for _ in range(3):
+                sim.step()
+            out[f"{tag}/dtypes3"] = np.array([str(sim.positions.dtype), str(sim.velocities.dtype), str(sim.masses.dtype),
+                                              str(sim.accelerations.dtype)])
+            out[f"{tag}/pos3"] = npy(sim.positions.double())
+            out[f"{tag}/vel3"] = npy(sim.velocities.double())
+            out[f"{tag}/e3"] = np.array([sim.get_kinetic_energy(), sim.get_potential_energy()])
+            out[f"{tag}/ok"] = np.array(1)
+        except Exception as exc:            # record what upstream does, including failing
+            out[f"{tag}/ok"] = np.array(0)
+            out[f"{tag}/error"] = np.array(type(exc).__name__ + ": " + str(exc)[:200])
+
+    for mode in MODES:
+        run(f"m64/{mode.value}", pos, vel, mass.double(), mode)                       # fp64 masses, fp32 positions
+        run(f"v64/{mode.value}", pos, vel.double(), mass, mode)                       # fp64 velocities only
+    for mode in (PrecisionMode.INT8_SIM, PrecisionMode.INT4_SIM, PrecisionMode.CUSTOM):
+        run(f"all64/{mode.value}", pos.double(), vel.double(), mass.double(), mode)   # grid modes on fp64 state
+        run(f"half/{mode.value}", pos.half(), vel.half(), mass.half(), mode)          # grid modes on float16 state
+        run(f"bf16/{mode.value}", pos.bfloat16(), vel.bfloat16(), mass.bfloat16(), mode)
+    np.savez_compressed(os.path.join(OUT, "g15_dtype_combos.npz"), **out)
+    for k in sorted(out):
+        if k.endswith("/ok") or k.endswith("/error") or k.endswith("dtypes0") or k.endswith("dtypes3"):
+            print(k, out[k])
+    print("G15")
+
+
 def g14():
     """The reference's own state hash (reproducibility.py:227-232) on golden states."""
     import reproducibility as ref_repro
@@ -645,6 +705,6 @@ def g14():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for w in which:
         globals()[w]()

@@ -399,9 +399,8 @@ def test_nan_inf_propagate_silently(nb):
 def test_errors_are_exceptions(nb):
     with pytest.raises(ValueError):
         nb.GalaxySimulation(torch.zeros(4, 4), torch.zeros(4, 4), torch.ones(4))
-    with pytest.raises(RuntimeError, match="not implemented"):       # documented gap: half-typed state + grid mode
-        nb.GalaxySimulation(torch.zeros(4, 2).half(), torch.zeros(4, 2).half(), torch.ones(4).half(),
-                            precision_mode=nb.PrecisionMode.INT8_SIM)
+    with pytest.raises(ValueError):
+        nb.GalaxySimulation(torch.zeros(4, 2), torch.zeros(5, 2), torch.ones(4))
 
 
 def test_rccl_path_with_one_rank_communicator():
@@ -1453,3 +1452,71 @@ def test_tensor_hooks_follow_the_callers_stream(nb):
     assert torch.equal(z.cpu(), ref)
     for _ in range(3):                            # repeated calls reuse the cached scratch
         assert torch.equal(Q._grid_quantize_safe(x, 256).cpu(), Q._grid_quantize_safe(x.cpu(), 256))
+
+
+# --------------------------------------------------------------------------- dtype combinations beyond the scripts (g15)
+_G15_TAGS = [f"{grp}/{m}" for grp in ("m64", "v64") for m in MODES] + \
+            [f"{grp}/{m}" for grp in ("all64", "half", "bf16") for m in GRID]
+
+
+@pytest.mark.parametrize("tag", _G15_TAGS)
+def test_g15_dtype_combinations_vs_reference(nb, tag):
+    """Every dtype combination the stock class accepts beyond what the scripts build, against the REFERENCE (g15):
+    fp64 masses / fp64 velocities beside fp32 positions under all seven modes, the grid modes on fp64 state and on
+    float16 / bfloat16 state.  dtype timeline identical; accelerations, energies and the state after three steps
+    to fp32 rounding (1e-12 for the all-fp64 chains); INT8 / INT4 forces within one force-grid step."""
+    g = load_golden("g15_dtype_combos.npz")
+    assert int(g[f"{tag}/ok"]) == 1
+    grp, mode = tag.split("/")
+    pos, vel, mass = T(g["pos"]), T(g["vel"]), T(g["mass"])
+    if grp == "m64":
+        mass = mass.double()
+    elif grp == "v64":
+        vel = vel.double()
+    elif grp == "all64":
+        pos, vel, mass = pos.double(), vel.double(), mass.double()
+    elif grp == "half":
+        pos, vel, mass = pos.half(), vel.half(), mass.half()
+    else:
+        pos, vel, mass = pos.bfloat16(), vel.bfloat16(), mass.bfloat16()
+    sim = nb.GalaxySimulation(pos, vel, mass, precision_mode=nb.PrecisionMode(mode), G=0.001, softening=0.1, dt=0.01)
+    names = lambda: [str(t.dtype) for t in (sim.positions, sim.velocities, sim.masses, sim.accelerations)]
+    assert names() == list(g[f"{tag}/dtypes0"])
+    tol = 1e-12 if grp == "all64" else 2e-6
+    if grp in ("half", "bf16"):
+        tol = 2e-2 if grp == "bf16" else 4e-3      # half-precision pair arithmetic: one ulp of the type per operation
+    acc = sim.accelerations.double().numpy()
+    ref = g[f"{tag}/acc0"]
+    if mode in ("int8_sim", "int4_sim") and f"{tag}/fmin" in g.files:
+        levels = 256 if mode == "int8_sim" else 16
+        step = (float(g[f"{tag}/fmax"]) - float(g[f"{tag}/fmin"])) / (levels - 1)
+        diff = np.abs(acc - ref)
+        assert diff.max() <= 1.01 * step + tol * np.abs(ref).max()
+        # half-typed pair arithmetic perturbs the summed forces by ~1e-3, comparable to a 256-level force-grid step
+        assert (diff > 0.5 * step).mean() < (0.1 if grp in ("half", "bf16") else 0.02)
+    else:
+        assert relerr(acc, ref) < tol, relerr(acc, ref)
+    ke, pe = sim.get_kinetic_energy(), sim.get_potential_energy()
+    etol = max(tol, 2e-6) if grp != "all64" else 1e-12
+    assert abs(ke - float(g[f"{tag}/e0"][0])) <= etol * abs(float(g[f"{tag}/e0"][0]))
+    assert abs(pe - float(g[f"{tag}/e0"][1])) <= etol * abs(float(g[f"{tag}/e0"][1]))
+    sim.run(3)
+    assert names() == list(g[f"{tag}/dtypes3"])
+    ptol = tol if mode not in ("int8_sim", "int4_sim") else max(tol, 1e-4)      # force-bin flips: dt^2 * one grid step
+    assert relerr(sim.positions.double().numpy(), g[f"{tag}/pos3"]) < ptol
+    assert relerr(sim.velocities.double().numpy(), g[f"{tag}/vel3"]) < max(ptol, 10 * tol if grp in ("half", "bf16") else ptol)
+
+
+def test_custom_levels_beyond_the_tables(nb):
+    """CUSTOM grids with more levels than the fused tables hold (sensitivity_test.py:149-162 sweeps to 65 536 and
+    beyond) run on the per-pair generic path -- O(N) memory, no N x N tensor -- and agree with the oracle's
+    restatement of the same evaluation."""
+    from oracle import oracle as O
+    g = load_golden("g1_n257_d2_e0.05.npz")
+    for L in (5000, 65536):
+        sim = mk(nb, g, "custom", custom_levels=L)
+        assert sim.force_kernel_name() == "generic_force_kernel"
+        ref = O.accelerations(g["pos"], g["mass"], "custom", softening=float(g["eps"]), levels=L)
+        assert relerr(sim.accelerations.numpy(), ref) < 2e-6
+        sim.run(2)
+        assert np.isfinite(sim.positions.numpy()).all()
