@@ -557,7 +557,10 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
     double s[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) s[k] = 0.0;
-#pragma unroll 4
+#ifndef NB_RED_UNROLL
+#define NB_RED_UNROLL 4
+#endif
+#pragma unroll NB_RED_UNROLL
     for (int c = g; c < total; c += NB_RED_WAVES) {
         if (c < ns) {                               // wave-uniform
 #pragma unroll
