@@ -218,6 +218,12 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                                          int rot_addr, const GridArgs &ga, int nsteps)
 {
     const f2 c15 = {1.5f, 1.5f}, one = {1.0f, 1.0f};
+    // table-free grid path: the two additive constants of its packed fmas live in VGPR pairs for the whole sweep
+    // (a packed op reads at most one SGPR pair: from SGPRs they cost a v_mov_b64 per use, 2 of ~23 VALU ops per unit)
+    f2 est_bc2 = {ga.est_bc, ga.est_bc}, c0c2 = {ga.c0c, ga.c0c};
+#ifndef NB_GRID_CONST_SGPR
+    if (HOOK == HOOK_GRID && (EST == GRID_FAST || EST == GRID_FAST_CLAMP)) asm volatile("" : "+v"(est_bc2), "+v"(c0c2));
+#endif
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
 #pragma unroll
@@ -239,7 +245,7 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                         // no table access for a wave whose 128 pairs all sit clear of the bin edges (the common case:
                         // an edge zone is ~1e-4 of a bin wide); the estimate is the one grid_tables_kernel validated
                         const f2 lg = {__builtin_amdgcn_logf(r2.x), __builtin_amdgcn_logf(r2.y)};
-                        const f2 ne = __builtin_elementwise_fma(lg, f2{ga.est_a, ga.est_a}, f2{ga.est_bc, ga.est_bc});
+                        const f2 ne = __builtin_elementwise_fma(lg, f2{ga.est_a, ga.est_a}, est_bc2);
                         f2 kf = {__builtin_rintf(ne.x), __builtin_rintf(ne.y)};
                         const f2 fr = ne - kf;
                         const float dev = __builtin_fmaxf(__builtin_fabsf(fr.x), __builtin_fabsf(fr.y));
@@ -249,7 +255,7 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                         } else {
                             if (EST == GRID_FAST_CLAMP)
                                 kf = f2{__builtin_amdgcn_fmed3f(kf.x, -ga.kcf, 1e30f), __builtin_amdgcn_fmed3f(kf.y, -ga.kcf, 1e30f)};
-                            const f2 th = __builtin_elementwise_fma(kf, f2{ga.c1, ga.c1}, f2{ga.c0c, ga.c0c});
+                            const f2 th = __builtin_elementwise_fma(kf, f2{ga.c1, ga.c1}, c0c2);
                             w = f2{__builtin_amdgcn_exp2f(th.x), __builtin_amdgcn_exp2f(th.y)};
                         }
                     } else if (EST == GRID_EST) {
