@@ -109,8 +109,11 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
     const double cyc_pair = (is_f64 ? 76.0 : 41.0) * (dim == 3 ? 19.0 / 14.0 : 1.0);
     const double sweep_us = 64.0 * sp.r * sp.r * cyc_pair / 2200.0;                      // one wave, whole SIMD
     const double force_us = ((double)T * (T + 1) / 2 / P) * sweep_us / (4.0 * in.cus);
+    // Default: ONE chunk.  Measured on MI355X / ROCm 7.2 (profiles/r02_chunk_pipeline_standin.txt): the cross-stream
+    // event hops a chunked step needs cost ~0.15-0.2 ms per step, more than the all-reduce latency they could hide at
+    // every size where that latency matters; NB_CHUNKS = 2..4 keeps the pipeline available (and tested).
     int C = 1;
-    if (in.multi) C = knobs.chunks > 0 ? knobs.chunks : (force_us >= 400.0 ? 2 : 1);
+    if (in.multi && knobs.chunks > 0) C = knobs.chunks;
     if (SR < 2 * C) C = 1;
     std::vector<int> bound(C + 1, 0);
     bound[C] = SR;
