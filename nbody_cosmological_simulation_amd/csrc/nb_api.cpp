@@ -160,6 +160,8 @@ struct nb_sim {
         double *rowslab = nullptr;
         std::vector<int> chunk_work, chunk_tile;      // pipeline chunks (host side, see nb_plan.h)
     } sym;
+    void *pos_alt = nullptr;             // small-N single-launch step: positions ping-pong between pos and pos_alt
+    double *small_part = nullptr;        // ... INT8 / INT4: per-target min / max of the forces (2 n doubles)
     void *gen_scalars = nullptr;         // generic (dtype-faithful) path: device scalars of one evaluation
     bool last_generic = false;           // the last force evaluation ran on the generic path (no threshold tables)
     void *metrics_scratch = nullptr;     // nb_metrics work arrays (allocated on first use)
@@ -719,6 +721,60 @@ int step_chunked(nb_sim *s, int nsteps, bool pending_close)
     return NB_OK;
 }
 
+// ---- small systems: one launch per step (nb_small.hip) ---------------------------------------------------------
+constexpr int NB_SMALL_MAX_DEFAULT = 4096;      // fp64: 4.9 / 7.9 / 11.4 / 16.9 us per step at N = 1024 / 2048 / 3000 / 4096
+bool small_ok(const nb_sim *s)
+{
+    const nb_config &c = s->cfg;
+    const int sdt = s->is_f64 ? NB_F64 : NB_F32;
+    const int nmax = s->knobs.small_max > 0 ? s->knobs.small_max : NB_SMALL_MAX_DEFAULT;
+    if (s->knobs.no_smalln || c.n > nmax || comm_active(s) || c.nranks != 1 || !s->have_acc) return false;
+    if (grid_mode(c.mode) && (s->is_f64 || mode_levels(c) > NB_LUT_MIN || mode_levels(c) < 2)) return false;
+    if (s->is_f64 != (c.mode == NB_FLOAT64)) return false;           // fp64 state under a cast mode: tuned one-sided kernel
+    // masses: fp32-typed masses in an fp64 run enter the fp64 product exactly (no rounding of their own); half-typed
+    // masses round the product to the half type and stay on the tuned kernels
+    const bool mass_ok = s->logical[2] == sdt || (s->is_f64 && s->logical[2] == NB_F32);
+    return s->logical[0] == sdt && s->logical[1] == sdt && mass_ok && s->logical[3] == sdt;
+}
+
+// the remaining `nsteps` steps of an nb_step call; `opened`: this step's opening kick + drift was already applied
+int step_small(nb_sim *s, int nsteps, bool opened)
+{
+    const nb_config &c = s->cfg;
+    const size_t el = s->is_f64 ? 8 : 4;
+    const bool grid = grid_mode(c.mode);
+    const bool fq = force_quant_mode(c);
+    if (!s->pos_alt) HIPCHK(hipMalloc(&s->pos_alt, (size_t)nd(s) * el));
+    if (fq && !s->small_part) HIPCHK(hipMalloc((void **)&s->small_part, 2 * (size_t)c.n * sizeof(double)));
+    const int hook = grid ? HOOK_GRID : (c.mode == NB_BFLOAT16 ? HOOK_BF16 : (c.mode == NB_FLOAT16 ? HOOK_F16 : HOOK_NONE));
+    const int lanes = s->knobs.small_lanes ? s->knobs.small_lanes : nb_small_lanes(c.n);
+    const float eps2f = (float)c.softening_sq;
+    if (!opened)
+        HIPCHK(nb_launch_kick_drift(s->pos, s->vel, s->acc, c.dt / 2, c.dt, nd(s), s->is_f64, s->stream));
+    for (int t = 0; t < nsteps; ++t) {
+        const bool last = (t + 1 == nsteps);
+        if (grid) {
+            // this evaluation's grid: all-pairs max of r2 (small N: one launch) and the threshold / factor tables
+            HIPCHK(nb_launch_r2max((const float *)s->pos, s->geom, c.dim, eps2f, s->tab, s->stream));
+            HIPCHK(nb_launch_grid_tables(s->tab, mode_levels(c), (float)c.G, eps2f, 0.01f, nullptr, s->stream,
+                                         s->knobs.no_grid_fast ? 0 : 1));
+        }
+        // INT8 / INT4: the forces are snapped to their grid (and the kicks applied) by the finish launch
+        const int kick = fq ? 0 : (last ? 1 : 2);
+        HIPCHK(nb_launch_small_step(s->pos, s->pos_alt, s->vel, s->acc, s->mass, c.n, c.dim, s->is_f64, hook, c.G,
+                                    c.softening_sq, c.dt / 2, c.dt, kick, lanes, s->stream, grid ? s->tab : nullptr,
+                                    fq ? s->small_part : nullptr));
+        if (fq)
+            HIPCHK(nb_launch_force_quant_finish((float *)s->acc, nd(s), mode_levels(c), s->small_part, c.n, s->scalars, s->fbins,
+                                                (float *)s->vel, (float *)s->pos, c.dt / 2, c.dt, last ? 1 : 2, s->stream));
+        else if (!last)
+            std::swap(s->pos, s->pos_alt);
+    }
+    s->last_kernel = "small_step_kernel";
+    s->last_generic = false;
+    return NB_OK;
+}
+
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(dev); }
@@ -782,7 +838,7 @@ int nb_destroy(nb_sim *s)
                     (void *)s->scratch, (void *)s->scalars, (void *)s->fbins, (void *)s->sym.work,
                     (void *)s->sym.row_slot0, (void *)s->sym.row_nslots, (void *)s->sym.col_upto,
                     (void *)s->sym.packed, (void *)s->sym.packed_alt, (void *)s->sym.rowslab, (void *)s->sym.colslab,
-                    (void *)s->prune_cand, (void *)s->prune_rho, (void *)s->prune_state, s->metrics_scratch, s->gen_scalars})
+                    (void *)s->prune_cand, (void *)s->prune_rho, (void *)s->prune_state, s->metrics_scratch, s->gen_scalars, s->pos_alt, (void *)s->small_part})
         if (p) (void)hipFree(p);
     if (s->prof_init)
         for (int i = 0; i < PROF_RING; ++i) { (void)hipEventDestroy(s->ev_start[i]); (void)hipEventDestroy(s->ev_stop[i]); }
@@ -904,6 +960,8 @@ int nb_step(nb_sim *s, int32_t nsteps)
     for (int t = 0; t < nsteps; ++t) {
         // multi-GPU, pair-symmetric, settled dtypes: the remaining steps run as pipelined chunks
         if (!opened && chunked_ok(s)) return step_chunked(s, nsteps - t, pending_close);
+        // small systems with settled dtypes: one launch per step
+        if (!pending_close && small_ok(s)) return step_small(s, nsteps - t, opened);
         // opening kick + drift; on the pair-symmetric path the repack rides in the same launch
         const int sdt = s->is_f64 ? NB_F64 : NB_F32;
         const bool fuse_pack = s->sym.enabled && s->logical[0] == sdt && s->logical[1] == sdt &&

@@ -205,3 +205,16 @@ hipError_t nb_launch_generic_force(const void *pos, const void *mass, int storag
                                    int dim, int P /* positions' dtype */, int M /* masses' dtype */, int mode, int levels,
                                    double G, double eps2_py, const void *sc, void *acc, int A /* result dtype */,
                                    hipStream_t st);
+
+// ---- one-launch step for small systems (nb_small.hip) -------------------------------------------------------------
+int nb_small_lanes(int n);
+hipError_t nb_launch_small_step(const void *pos_in, void *pos_out, void *vel, void *acc, const void *mass, int n, int dim,
+                                int is_f64, int hook, double G, double eps2, double half_dt, double dt,
+                                int do_kick /* 0 force only, 1 + closing kick, 2 + next opening kick + drift into pos_out */,
+                                int lanes /* 16 / 32 / 64 lanes per target */, hipStream_t st,
+                                const GridTables *tab = nullptr /* HOOK_GRID: this evaluation's tables */,
+                                double *part = nullptr /* INT8 / INT4: 2 n doubles, per-target min / max of the forces */);
+// second half of nb_launch_force_quant_step with caller-provided min / max partials (nblocks pairs of doubles)
+hipError_t nb_launch_force_quant_finish(float *acc, int64_t count, int levels, const double *partials, int nblocks,
+                                        double *mn_mx, int16_t *bins, float *vel, float *pos, double half_dt, double dt,
+                                        int kick, hipStream_t st);

@@ -24,6 +24,8 @@ struct NbKnobs {
     bool no_pe_sym = false;  // NB_NO_PE_SYM: one-sided potential-energy kernel
     bool no_uniform = false; // NB_NO_UNIFORM: general-mass kernels even for equal masses
     bool no_smalln = false;  // NB_NO_SMALLN: never use the single-launch small-N step
+    int small_max = 0;       // NB_SMALL_MAX: largest N of the single-launch step (0 = default), NB_SMALL_LANES: lanes per target
+    int small_lanes = 0;
     bool no_grid_fast = false;   // NB_NO_GRID_FAST: grid modes always read their tables (A/B of the table-free pair path)
 };
 NbKnobs nb_read_knobs();
