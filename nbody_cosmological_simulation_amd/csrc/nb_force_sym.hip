@@ -266,18 +266,30 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                         w.y = ga.lut[grid_bin_lookup(ga.thr, r2.y, ga.lp)];
                     }
                 } else {
-                    f2 q = r2;
-                    if (HOOK == HOOK_BF16) q = f2{(float)(__bf16)r2.x, (float)(__bf16)r2.y};
-                    if (HOOK == HOOK_F16) q = f2{(float)(_Float16)r2.x, (float)(_Float16)r2.y};
-                    const f2 y0 = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
-                    const f2 y02 = y0 * y0;
-                    const f2 e = __builtin_elementwise_fma(-q, y02, one);
-                    const f2 v = y0 * y02;
-                    const f2 ve = v * e;
-                    w = __builtin_elementwise_fma(ve, c15, v);
-                    if (HOOK == HOOK_F16) {      // fp16 overflow: q = +inf -> zero force upstream
-                        w.x = (q.x == __builtin_inff()) ? 0.0f : w.x;
-                        w.y = (q.y == __builtin_inff()) ? 0.0f : w.y;
+                    if constexpr (HOOK == HOOK_BF16 || HOOK == HOOK_F16) {
+                        // BFLOAT16 / FLOAT16 hooks: q carries 8 / 11 significant bits, so the 1-ulp v_rsq_f32 cubed
+                        // (<= 3 ulp of fp32, 2e-7) is already four orders of magnitude below the hook's own rounding
+                        // of r2 -- no Newton correction.  That also serves fp16 overflow for free: q = +inf gives
+                        // v_rsq_f32 = 0, w = 0, which is what upstream's G / inf**1.5 yields (the corrected form would
+                        // produce inf * 0).  Packed conversion to the half type (v_cvt_pk_*; round to nearest even).
+                        f2 q;
+                        if constexpr (HOOK == HOOK_BF16) {
+                            typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                            q = __builtin_convertvector(__builtin_convertvector(r2, b2), f2);
+                        } else {
+                            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                            q = __builtin_convertvector(__builtin_convertvector(r2, h2), f2);
+                        }
+                        const f2 y0 = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+                        w = y0 * (y0 * y0);
+                    } else {
+                        const f2 q = r2;
+                        const f2 y0 = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+                        const f2 y02 = y0 * y0;
+                        const f2 e = __builtin_elementwise_fma(-q, y02, one);
+                        const f2 v = y0 * y02;
+                        const f2 ve = v * e;
+                        w = __builtin_elementwise_fma(ve, c15, v);
                     }
                 }
                 const f2 wj = UNIFORM ? w : w * gj2[h];
