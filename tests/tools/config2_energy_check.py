@@ -7,7 +7,7 @@ Prints the energy drift of both every 500 ticks, their difference, and the posit
 """
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, __file__.rsplit("/", 2)[0])
+sys.path.insert(0, __import__("os").path.abspath(__file__).rsplit("/", 3)[0])
 import nbody_cosmological_simulation_amd as nb
 from nbody_cosmological_simulation_amd import galaxy
 from oracle import oracle as O

@@ -1,3 +1,6 @@
+"""A/B of the grid modes' table-free pair path against the table path (NB_NO_GRID_FAST) on single evaluations, and both
+against the oracle.  Test infrastructure (it uses the oracle): run from the repo root on a GPU box,
+    python tests/tools/grid_fast_ab.py"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 import nbody_cosmological_simulation_amd as nb

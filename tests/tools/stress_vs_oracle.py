@@ -4,7 +4,7 @@ softening, G, dt, masses, kernel family, tile shape, steps and step batching are
     python tools/stress_vs_oracle.py SEED CASES
 """
 import os, sys, numpy as np, torch
-sys.path.insert(0, __file__.rsplit("/", 2)[0])
+sys.path.insert(0, __import__("os").path.abspath(__file__).rsplit("/", 3)[0])
 import nbody_cosmological_simulation_amd as nb
 from oracle import oracle as O
 def relerr(a, b):
