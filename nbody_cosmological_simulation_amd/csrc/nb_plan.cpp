@@ -55,7 +55,9 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
     const bool tiny = is_f64 && dim == 2 && n <= 2816;
     // fp32 family: R = 2 already wins at N = 1024 (14.2 vs 15.4 us; INT4 51 vs 62).  3-D crosses over later
     // (fp64: 8192 56.9 one-sided vs 60.5, 12288 131 vs 92.6; fp32: 3000 19.8 vs 20.0, 8192 52.3 vs 36.0).
-    const int sym_from = dim == 3 ? (is_f64 ? 10240 : 4096) : (is_f64 ? 5120 : 1024);
+    // round 2: with the sweeps of mid-sized systems cut into pieces (below) the 3-D fp64 crossover moves down to 8192
+    // (50.5 us per step against 57 one-sided)
+    const int sym_from = dim == 3 ? (is_f64 ? 8192 : 4096) : (is_f64 ? 5120 : 1024);
     int want = (tiny || n >= sym_from) ? 1 : 0;
     if (knobs.sym >= 0) want = knobs.sym;
     // comm-less shards (NB_FLAG_NO_COMM) use the one-sided kernel unless NB_SYM=2 asks for the symmetric
@@ -64,7 +66,11 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
     if (is_f64 && in.mode != NB_FLOAT64) return;    // fp64 state under a cast / grid mode: one-sided kernel
     // targets per lane.  Measured on MI355X, N=65536, D=2: R=1 3.39 ms, R=2 1.87 ms, R=4 1.47 ms.  D=3 also keeps
     // four targets per lane and sweeps the source tile in two halves of two slots (sym_rj, nb_force_sym.hip)
-    sp.r = tiny ? 1 : (n < 20480) ? 2 : 4;
+    // fp64 mid sizes (5120 ... 20 479) also take R = 4 since round 2: 16 pairs per rotation step hide the rotation's
+    // latency better than 4, and the missing parallelism comes from cutting every sweep into pieces instead (us per
+    // step, R = 2 whole sweeps -> R = 4 in four pieces: N = 8192 44.3 -> 39.1, 12 288 68.8 -> 60.9, 16 384 113.5 -> 96.7;
+    // 3-D: 12 288 96.4 -> 76.2, 16 384 158 -> 124).  fp32 keeps R = 2 there (R = 4 in pieces: 41.5 vs 40.3 at 12 288).
+    sp.r = tiny ? 1 : (n >= 20480 || is_f64) ? 4 : 2;
     if ((knobs.sym_r == 1 && is_f64 && dim == 2) || knobs.sym_r == 2 || knobs.sym_r == 4) sp.r = knobs.sym_r;
     sp.tile_b = 64 * sp.r;
     const int T = (n + sp.tile_b - 1) / sp.tile_b;            // tiles that hold particles
@@ -145,6 +151,14 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
         if (ord[S] >= 0) { nch_of[S] = (T - 4 * S + cl - 1) / cl; items += nch_of[S]; }
     if (knobs.sym_split) {
         for (int S = 0; S < SR; ++S) split_of[S] = knobs.sym_split;
+    } else if (sp.r == 4 && items < 1000) {
+        // Mid-sized systems on the R = 4 tiling: too few work items to fill 1024 workgroup slots with four waves per SIMD,
+        // and a whole sweep (64 steps x 16 pairs) is long -- every sweep in 4 pieces (8 below 100 items).  Measured
+        // fp64 us per step with 1 / 2 / 4 / 8 pieces: N = 6144 (84 items) 51.4 / 30.2 / 28.5 / 27.9, 8192 (144) 52.3 /
+        // 45.4 / 39.1 / 39.9, 12 288 (312) 81.1 / 65.6 / 60.9 / 62.7, 16 384 (544) 116 / 102 / 96.7 / 101,
+        // 24 576 (1200) 192 / 195 / 196 / 216.
+        const int pieces = items < 100 ? 8 : 4;
+        for (int S = 0; S < SR; ++S) split_of[S] = pieces;
     } else if (items <= 100) {
         // Very small systems are bound by the LATENCY of one 64-step sweep (~4 us: a bpermute + a dependent VALU chain
         // per step), not by throughput: a few dozen workgroups leave most of the chip idle.  Cutting every sweep into
@@ -152,6 +166,10 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
         // with 1 / 2 / 4 / 8 pieces; N = 2048, 144 items: no gain).
         const int pieces = items < 24 ? 8 : (items <= 64 ? 4 : 2);
         for (int S = 0; S < SR; ++S) split_of[S] = pieces;
+    } else if (sp.r == 2 && !is_f64 && items < 400) {
+        // fp32, R = 2, a few hundred items: two pieces (us per step 1 / 2 / 4 pieces: N = 4096 15.9 / 13.8 / 14.7,
+        // 6144 20.2 / 18.6 / 21.6; 8192 (544 items) 26.3 / 26.1 / 30.8)
+        for (int S = 0; S < SR; ++S) split_of[S] = 2;
     } else if (items > wg_slots / 2) {
         long long rem = items % wg_slots;
         // a single round of workgroups has nothing to hide a straggler behind: finer pieces there
