@@ -764,8 +764,9 @@ int step_small(nb_sim *s, int nsteps, bool opened)
         HIPCHK(nb_launch_small_step(s->pos, s->pos_alt, s->vel, s->acc, s->mass, c.n, c.dim, s->is_f64, hook, c.G,
                                     c.softening_sq, c.dt / 2, c.dt, kick, lanes, s->stream, grid ? s->tab : nullptr,
                                     fq ? s->small_part : nullptr));
-        if (fq)
-            HIPCHK(nb_launch_force_quant_finish((float *)s->acc, nd(s), mode_levels(c), s->small_part, c.n, s->scalars, s->fbins,
+        if (fq)      // one min / max pair per workgroup of the force launch
+            HIPCHK(nb_launch_force_quant_finish((float *)s->acc, nd(s), mode_levels(c), s->small_part,
+                                                (c.n + NB_BLOCK / lanes - 1) / (NB_BLOCK / lanes), s->scalars, s->fbins,
                                                 (float *)s->vel, (float *)s->pos, c.dt / 2, c.dt, last ? 1 : 2, s->stream));
         else if (!last)
             std::swap(s->pos, s->pos_alt);
