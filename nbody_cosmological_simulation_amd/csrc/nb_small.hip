@@ -54,7 +54,6 @@ small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__re
 {
     constexpr bool F64 = sizeof(T) == 8;
     constexpr int TG = NB_BLOCK / S;                 // targets per workgroup
-    constexpr int SM_UNROLL = (HOOK == HOOK_GRID) ? 1 : 4;
     __shared__ T sx[D][SM_TILE];
     __shared__ T sg[SM_TILE];                        // G * m_j (fp32: the reference's (1/p * G) * m_j order is kept below)
     // grid hook (INT8 / INT4 / CUSTOM up to 256 levels): the evaluation's tables (nb_force.hip grid_tables_kernel)
@@ -88,7 +87,9 @@ small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__re
 
     for (int j0 = 0; j0 < n; j0 += SM_TILE) {
         __syncthreads();
-        const int cnt_ld = (min(SM_TILE, n - j0) + S - 1) / S * S;   // entries past the end: padding (far away, massless)
+        // entries past the end, up to the pair loop's stride: padding (far away, massless)
+        constexpr int STRIDE = (HOOK == HOOK_GRID) ? 4 * S : S;
+        const int cnt_ld = min(SM_TILE, (min(SM_TILE, n - j0) + STRIDE - 1) / STRIDE * STRIDE);
         // (a "flat" variant -- consecutive threads reading consecutive elements of the (N, D) array and scattering them
         // into the component arrays -- measured slower on the same box: 6.8 vs 5.4 us per step at N = 1024 fp64)
         for (int t = tid; t < cnt_ld; t += NB_BLOCK) {
@@ -104,9 +105,59 @@ small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__re
             }
         }
         __syncthreads();
-        const int cnt = min(SM_TILE, n - j0);
-        const int cnt_up = (cnt + S - 1) / S * S;    // padding entries are harmless
-#pragma unroll SM_UNROLL
+        const int cnt_up = cnt_ld;                   // padding entries are harmless
+        if constexpr (HOOK == HOOK_GRID) {
+            // four sources per iteration: independent log / exp chains in flight, ONE edge test for all of them
+            constexpr int U = 4;
+            for (int jj = l; jj < cnt_up; jj += U * S) {
+                float dd[U][D], q[U], w[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) dd[u][k] = __fsub_rn(sx[k][jj + u * S], xi[k]);
+                    q[u] = r2_f32_exact<D>(dd[u], eps2);
+                }
+                // (1 / q_k^1.5) * G of each pair's bin: table-free when no pair of the wave sits on a bin edge
+                // (DESIGN.md section 4.3), else floor(estimate) + one threshold compare, else binary search
+                if (g_deg) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) w[u] = __fmul_rn(inv_r3_f(q[u] < 0.01f ? 0.01f : q[u]), G);
+                } else if (g_fast) {
+                    float kf[U], dev = 0.0f;
+                    bool bad = false;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float ne = __builtin_fmaf(__builtin_amdgcn_logf(q[u]), est_a, est_bc);
+                        kf[u] = __builtin_rintf(ne);
+                        const float dv = __builtin_fabsf(ne - kf[u]);
+                        bad |= !(dv <= sure_lim);                                 // also true for NaN
+                        dev = __builtin_fmaxf(dev, dv);
+                    }
+                    if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            w[u] = s_lut[grid_bin_floor_estimate(s_thr, q[u], est_a, est_b, g_levels - 2)];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u)          // max(): softening^2 below the grid's floor
+                            w[u] = ldexpf(__builtin_amdgcn_exp2f(__builtin_fmaf(__builtin_fmaxf(kf[u], -kcf), c1, c0c)), g_tm);
+                    }
+                } else if (g_est) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) w[u] = s_lut[grid_bin_floor_estimate(s_thr, q[u], est_a, est_b, g_levels - 2)];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) w[u] = s_lut[grid_bin_lookup(s_thr, q[u], NB_LUT_MIN)];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float wm = __fmul_rn(w[u], sg[jj + u * S]);
+#pragma unroll
+                    for (int k = 0; k < D; ++k) a[k] += (double)__fmul_rn(wm, dd[u][k]);
+                }
+            }
+        } else {
+#pragma unroll 4
         for (int jj = l; jj < cnt_up; jj += S) {
             T d[D];
             if constexpr (F64) {
@@ -124,35 +175,13 @@ small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__re
                 float q = r2_f32_exact<D>(d, eps2);
                 if (HOOK == HOOK_BF16) q = round_bf16(q);
                 if (HOOK == HOOK_F16) q = round_f16(q);
-                float w;
-                if constexpr (HOOK == HOOK_GRID) {
-                    // (1 / q_k^1.5) * G of the pair's bin: table-free when no pair of the wave sits on a bin edge
-                    // (DESIGN.md section 4.3), else floor(estimate) + one threshold compare, else binary search
-                    if (g_deg) {
-                        w = __fmul_rn(inv_r3_f(q < 0.01f ? 0.01f : q), G);
-                    } else if (g_fast) {
-                        const float ne = __builtin_fmaf(__builtin_amdgcn_logf(q), est_a, est_bc);
-                        float kf = __builtin_rintf(ne);
-                        const float dev = __builtin_fabsf(ne - kf);
-                        if (__builtin_amdgcn_ballot_w64(!(dev <= sure_lim)) != 0ull) {
-                            w = s_lut[grid_bin_floor_estimate(s_thr, q, est_a, est_b, g_levels - 2)];
-                        } else {
-                            kf = __builtin_fmaxf(kf, -kcf);                       // softening^2 below the grid's floor
-                            w = ldexpf(__builtin_amdgcn_exp2f(__builtin_fmaf(kf, c1, c0c)), g_tm);
-                        }
-                    } else if (g_est) {
-                        w = s_lut[grid_bin_floor_estimate(s_thr, q, est_a, est_b, g_levels - 2)];
-                    } else {
-                        w = s_lut[grid_bin_lookup(s_thr, q, NB_LUT_MIN)];
-                    }
-                } else {
-                    w = __fmul_rn(inv_r3_f(q), G);
-                    if (HOOK == HOOK_F16) w = (q == __builtin_inff()) ? 0.0f : w;  // pow(inf) = inf -> G / inf = 0 upstream
-                }
+                float w = __fmul_rn(inv_r3_f(q), G);
+                if (HOOK == HOOK_F16) w = (q == __builtin_inff()) ? 0.0f : w;      // pow(inf) = inf -> G / inf = 0 upstream
                 w = __fmul_rn(w, sg[jj]);
 #pragma unroll
                 for (int k = 0; k < D; ++k) a[k] += (double)__fmul_rn(w, d[k]);
             }
+        }
         }
     }
     // the S lanes of a target: fixed butterfly
