@@ -479,14 +479,11 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
     bool used_sym = false, sym_uniform = false;
 
     if (s->is_f64) {
-        if (grid_mode(c.mode))
-            return fail(NB_ERR_UNSUPPORTED, "fp64 state with a grid precision mode is not implemented");
+        // (grid modes on fp64 storage and cast modes before the positions are promoted took the generic path above)
         int qhook = -1;                      // fp64 positions under a cast mode: hook output is fp32
         if (c.mode == NB_FLOAT32) qhook = HOOK_NONE;
         else if (c.mode == NB_BFLOAT16) qhook = HOOK_BF16;
         else if (c.mode == NB_FLOAT16) qhook = HOOK_F16;
-        if (qhook >= 0 && s->logical[0] != NB_F64)
-            return fail(NB_ERR_UNSUPPORTED, "mixed fp32 positions in fp64 storage under a cast mode");
         const int pair_dt = (qhook < 0 && s->logical[0] != NB_F64) ? s->logical[0] : -1;   // NB_F32 / F16 / BF16
         const int pa_f32 = (pair_dt == NB_F32);
         const bool sym_default_shape = s->sym.r == 4 || s->sym.r == 2;   // HOOK_F32PAIR instantiations
@@ -517,8 +514,6 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         else if (grid_mode(c.mode)) hook = HOOK_GRID;
         const int pa = is_half(s->logical[0]) ? s->logical[0] : NB_F32;   // half-typed positions (first evaluation)
         const float eps2 = (float)round_dt(pa, c.softening_sq);
-        if (pa != NB_F32 && hook == HOOK_GRID)
-            return fail(NB_ERR_UNSUPPORTED, "grid modes on float16/bfloat16 state are not implemented");
         if (hook == HOOK_GRID) {
             const int L = mode_levels(c);
             if (L > NB_MAX_LUT || L < 2)
