@@ -1532,7 +1532,8 @@ def test_two_rank_rccl_step_matches_single_gpu(nb):
     import subprocess
     import sys
     import tempfile
-    if nb._native.device_count() < 2:
+    nproc = int(os.environ.get("NB_TWO_RANK_NPROC", "2"))      # 1: plumbing check of this test's script on a one-GPU box
+    if nb._native.device_count() < nproc:
         pytest.skip("needs two GPUs")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = r'''
@@ -1572,16 +1573,18 @@ if rank == 0:
         open(path, "w").write(script)
         outp = os.path.join(tmp, "out.json")
         env = dict(os.environ, NB_ROOT=root, NB_OUT=outp, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if nproc == 1:
+            env["NBODY_FORCE_COMM"] = "1"      # our 1-rank RCCL communicator beside torch's NCCL process group
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             env.pop(k, None)
-        res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+        res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
                               "--master-addr", "127.0.0.1", "--master-port", "29731", path], env=env,
                              capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
         ranks = json.load(open(outp))
-    assert len(ranks) == 2
+    assert len(ranks) == nproc
     for name in ("f64", "f32", "int4", "int4_big"):
-        a, b = ranks[0][name], ranks[1][name]
+        a, b = ranks[0][name], ranks[-1][name]
         assert a["hash"] == b["hash"], f"{name}: the two ranks hold different states"
         tol = 1e-12 if name == "f64" else (2e-6 if name == "f32" else 1e-4)
         assert a["relerr"] < tol, (name, a["relerr"])
