@@ -217,7 +217,9 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                                          f2 (&xj2)[RJ / 2][D], f2 (&gj2)[RJ / 2], f2 (&aj2)[RJ / 2][D], float eps2,
                                          int rot_addr, const GridArgs &ga, int nsteps)
 {
+#ifdef NB_F32_CORR
     const f2 c15 = {1.5f, 1.5f}, one = {1.0f, 1.0f};
+#endif
     // table-free grid path: the two additive constants of its packed fmas live in VGPR pairs for the whole sweep
     // (a packed op reads at most one SGPR pair: from SGPRs they cost a v_mov_b64 per use, 2 of ~23 VALU ops per unit)
     f2 est_bc2 = {ga.est_bc, ga.est_bc}, c0c2 = {ga.c0c, ga.c0c};
@@ -283,13 +285,24 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                         const f2 y0 = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
                         w = y0 * (y0 * y0);
                     } else {
+                        // FLOAT32 hook: the 1-ulp v_rsq_f32 cubed, no Newton correction (round 2).  Measured against the
+                        // exact fp64 forces at N = 30 000 (tests/tools/f32_accuracy.py, relative to the force scale): the
+                        // reference's own fp32 arithmetic (oracle) max 1.05e-7 / rms 1.51e-8; this kernel WITH the
+                        // first-order correction 1.26e-7 / 1.61e-8, WITHOUT 1.23e-7 / 1.21e-8 -- the error of the summed
+                        // forces is set by the fp32 roundings of the differences, r2 and the products, not by the last
+                        // ulp of q^-3/2, so the three packed ops of the correction bought nothing (0.657 -> 0.556 ms per
+                        // launch at N = 65 536).  NB_F32_CORR restores it for A/B measurements.
                         const f2 q = r2;
                         const f2 y0 = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
                         const f2 y02 = y0 * y0;
+#ifdef NB_F32_CORR
                         const f2 e = __builtin_elementwise_fma(-q, y02, one);
                         const f2 v = y0 * y02;
                         const f2 ve = v * e;
                         w = __builtin_elementwise_fma(ve, c15, v);
+#else
+                        w = y0 * y02;
+#endif
                     }
                 }
                 const f2 wj = UNIFORM ? w : w * gj2[h];
