@@ -235,9 +235,24 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                 f2 d[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) d[k] = xj2[h][k] - xi[ri][k];
-                f2 r2 = d[0] * d[0] + d[1] * d[1];          // one rounding per op (contraction is off)
-                if (D == 3) r2 = r2 + d[2] * d[2];
-                r2 = r2 + eps2;
+                f2 r2;
+#ifndef NB_F32_R2_EXACT
+                if constexpr (HOOK == HOOK_NONE) {
+                    // FLOAT32 mode has no rounding DECISION hanging on r2 (no bins, no half-type cast), so r2 is built with
+                    // fused multiply-adds: D packed ops instead of 2 D, and closer to the exact r2 than the reference's
+                    // separately rounded sum (summed forces vs exact: rms 1.12e-8 against 1.21e-8 with the unfused form and
+                    // 1.51e-8 for the reference's own fp32 arithmetic; tests/tools/f32_accuracy.py).  0.581 -> 0.532 ms per
+                    // launch on the same box.  Every hook that DOES round r2 keeps the reference's r2 bit for bit, below.
+                    r2 = __builtin_elementwise_fma(d[D - 1], d[D - 1], f2{eps2, eps2});
+#pragma unroll
+                    for (int k = D - 2; k >= 0; --k) r2 = __builtin_elementwise_fma(d[k], d[k], r2);
+                } else
+#endif
+                {
+                    r2 = d[0] * d[0] + d[1] * d[1];         // one rounding per op (contraction is off): the reference's r2, bit for bit
+                    if (D == 3) r2 = r2 + d[2] * d[2];
+                    r2 = r2 + eps2;
+                }
                 f2 w;
                 if (HOOK == HOOK_GRID) {
                     if (EST == GRID_DEGENERATE) {
