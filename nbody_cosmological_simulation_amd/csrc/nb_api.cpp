@@ -170,6 +170,8 @@ struct nb_sim {
     // chunked multi-GPU step: second force stream, collective stream, events
     hipStream_t fstream2 = nullptr, cstream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr, ev_force[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipGraphExec_t chunk_graph_exec = nullptr;       // two chunked steps (A -> B -> A), captured once
+    double chunk_graph_key[4] = {0, 0, 0, 0};        // G, softening^2, dt, uniform mass the graph was captured with
     ncclComm_t comm = nullptr;
     // profiling
     hipEvent_t ev_start[PROF_RING], ev_stop[PROF_RING];
@@ -631,6 +633,9 @@ int ensure_chunk_streams(nb_sim *s)
     if (s->cstream) return NB_OK;
     int least = 0, greatest = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // stream priorities HURT here (measured: P = 2 stand-in 0.84 ms per step with a high-priority collective stream and
+    // a low-priority second force stream against 0.68 with equal priorities): off unless NB_CHUNK_PRIO=1
+    if (!s->knobs.chunk_prio) least = greatest = 0;
     HIPCHK(hipStreamCreateWithPriority(&s->cstream, hipStreamNonBlocking, greatest));
     HIPCHK(hipStreamCreateWithPriority(&s->fstream2, hipStreamNonBlocking, least));
     HIPCHK(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
@@ -660,9 +665,10 @@ int launch_sym_range(nb_sim *s, const void *packed, int w0, int nw, hipStream_t 
 
 // `nsteps` leapfrog steps; on entry the accelerations are complete and, if pending_close, the closing half
 // kick of the previous step is still due.  On exit everything is applied and the main stream has joined.
-int step_chunked(nb_sim *s, int nsteps, bool pending_close)
+// one chunked step: forces of all chunks on the force streams, per chunk (in order) reduction + all-reduce slice + kicks /
+// drift / repack into `pk_next` on the collective stream; joins back into the main stream
+int enqueue_chunk_step(nb_sim *s, bool last, void *pk_cur, void *pk_next)
 {
-    if (int rc = ensure_chunk_streams(s)) return rc;
     const nb_config &c = s->cfg;
     auto &sp = s->sym;
     const int C = (int)sp.chunk_tile.size() - 1;
@@ -671,45 +677,79 @@ int step_chunked(nb_sim *s, int nsteps, bool pending_close)
     const size_t el = s->is_f64 ? 8 : 4;
     double scale = 1.0;
     if (s->mass_uniform) scale = s->is_f64 ? c.G * s->mass_value : (double)((float)c.G * (float)s->mass_value);
+    HIPCHK(hipEventRecord(s->ev_ready, s->stream));
+    HIPCHK(hipStreamWaitEvent(s->fstream2, s->ev_ready, 0));
+    for (int ch = 0; ch < C; ++ch) {
+        hipStream_t fs = ((ch & 1) && !s->knobs.chunk_serial) ? s->fstream2 : s->stream;
+        if (int rc = launch_sym_range(s, pk_cur, sp.chunk_work[ch], sp.chunk_work[ch + 1] - sp.chunk_work[ch], fs)) return rc;
+        HIPCHK(hipEventRecord(s->ev_force[ch], fs));
+    }
+    for (int ch = 0; ch < C; ++ch) {
+        const int p0 = sp.chunk_tile[ch] * sp.tile_b;
+        const int p1 = std::min(sp.chunk_tile[ch + 1] * sp.tile_b, c.n);
+        HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_force[ch], 0));
+        if (p1 > p0) {
+            HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.col_upto, sp.tile_b, c.n,
+                                        sp.np, c.dim, s->is_f64, scale, s->acc, s->vel, half_dt, 0, s->pos, pk_cur,
+                                        c.dt, s->cstream, p0, p1));
+            char *a = (char *)s->acc + (size_t)p0 * c.dim * el;
+            NCCLCHK(g_rccl.AllReduce(a, a, (size_t)(p1 - p0) * c.dim, s->is_f64 ? ncclDouble : ncclFloat, ncclSum, s->comm,
+                                     s->cstream));
+        }
+        if (!last) {
+            // closing kick, the next step's opening kick + drift, repack into the other buffer (the force
+            // streams may still be reading this step's positions from pk_cur)
+            const int pe = (ch == C - 1) ? sp.np : sp.chunk_tile[ch + 1] * sp.tile_b;
+            HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, pk_next, c.n, sp.np, c.dim, s->is_f64, 2, half_dt,
+                                  c.dt, gfac, 0, s->cstream, p0, pe));
+        } else if (p1 > p0) {
+            HIPCHK(nb_launch_axpy((char *)s->vel + (size_t)p0 * c.dim * el, (char *)s->acc + (size_t)p0 * c.dim * el,
+                                  half_dt, (int64_t)(p1 - p0) * c.dim, s->is_f64, s->cstream));
+        }
+    }
+    HIPCHK(hipEventRecord(s->ev_done, s->cstream));
+    HIPCHK(hipStreamWaitEvent(s->stream, s->ev_done, 0));
+    return NB_OK;
+}
+
+// `nsteps` leapfrog steps; on entry the accelerations are complete and, if pending_close, the closing half
+// kick of the previous step is still due.  On exit everything is applied and the main stream has joined.
+// Pairs of steps (A -> B -> A buffers) are captured ONCE into a hipGraph and replayed: the fork / join of the three
+// streams then costs one graph launch instead of a dozen event records / waits per step (NB_CHUNK_GRAPH=0: eager).
+int step_chunked(nb_sim *s, int nsteps, bool pending_close)
+{
+    if (int rc = ensure_chunk_streams(s)) return rc;
+    const nb_config &c = s->cfg;
+    auto &sp = s->sym;
+    const double half_dt = c.dt / 2;
+    const double gfac = s->is_f64 ? c.G : (double)(float)c.G;
     // opening kick + drift + pack of the first step (whole range, main stream)
     HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, s->is_f64, pending_close ? 2 : 1,
                           half_dt, c.dt, gfac, 0, s->stream));
-    for (int t = 0; t < nsteps; ++t) {
+    int t = 0;
+    if (s->knobs.chunk_graph && nsteps >= 3) {
+        const double key[4] = {c.G, c.softening_sq, c.dt, s->mass_uniform ? s->mass_value : -1.0};
+        if (s->chunk_graph_exec && memcmp(key, s->chunk_graph_key, sizeof key) != 0) {
+            (void)hipGraphExecDestroy(s->chunk_graph_exec);
+            s->chunk_graph_exec = nullptr;
+        }
+        if (!s->chunk_graph_exec) {
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
+            int rc = enqueue_chunk_step(s, false, sp.packed, sp.packed_alt);
+            if (!rc) rc = enqueue_chunk_step(s, false, sp.packed_alt, sp.packed);
+            const hipError_t e = hipStreamEndCapture(s->stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            HIPCHK(e);
+            HIPCHK(hipGraphInstantiate(&s->chunk_graph_exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            memcpy(s->chunk_graph_key, key, sizeof key);
+        }
+        for (; t + 2 < nsteps; t += 2) HIPCHK(hipGraphLaunch(s->chunk_graph_exec, s->stream));
+    }
+    for (; t < nsteps; ++t) {
         const bool last = (t + 1 == nsteps);
-        HIPCHK(hipEventRecord(s->ev_ready, s->stream));
-        HIPCHK(hipStreamWaitEvent(s->fstream2, s->ev_ready, 0));
-        HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_ready, 0));
-        for (int ch = 0; ch < C; ++ch) {
-            hipStream_t fs = (ch & 1) ? s->fstream2 : s->stream;
-            if (int rc = launch_sym_range(s, sp.packed, sp.chunk_work[ch], sp.chunk_work[ch + 1] - sp.chunk_work[ch], fs)) return rc;
-            HIPCHK(hipEventRecord(s->ev_force[ch], fs));
-        }
-        for (int ch = 0; ch < C; ++ch) {
-            const int p0 = sp.chunk_tile[ch] * sp.tile_b;
-            const int p1 = std::min(sp.chunk_tile[ch + 1] * sp.tile_b, c.n);
-            HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_force[ch], 0));
-            if (p1 > p0) {
-                HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.col_upto, sp.tile_b, c.n,
-                                            sp.np, c.dim, s->is_f64, scale, s->acc, s->vel, half_dt, 0, s->pos, sp.packed,
-                                            c.dt, s->cstream, p0, p1));
-                char *a = (char *)s->acc + (size_t)p0 * c.dim * el;
-                NCCLCHK(g_rccl.AllReduce(a, a, (size_t)(p1 - p0) * c.dim, s->is_f64 ? ncclDouble : ncclFloat, ncclSum, s->comm,
-                                         s->cstream));
-            }
-            if (!last) {
-                // closing kick, the next step's opening kick + drift, repack into the other buffer (the force
-                // streams may still be reading this step's positions from sp.packed)
-                const int pe = (ch == C - 1) ? sp.np : sp.chunk_tile[ch + 1] * sp.tile_b;
-                HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed_alt, c.n, sp.np, c.dim, s->is_f64, 2, half_dt,
-                                      c.dt, gfac, 0, s->cstream, p0, pe));
-            } else if (p1 > p0) {
-                HIPCHK(nb_launch_axpy((char *)s->vel + (size_t)p0 * c.dim * el, (char *)s->acc + (size_t)p0 * c.dim * el,
-                                      half_dt, (int64_t)(p1 - p0) * c.dim, s->is_f64, s->cstream));
-            }
-        }
-        HIPCHK(hipEventRecord(s->ev_done, s->cstream));
-        HIPCHK(hipStreamWaitEvent(s->stream, s->ev_done, 0));
-        HIPCHK(hipStreamWaitEvent(s->fstream2, s->ev_done, 0));
+        if (int rc = enqueue_chunk_step(s, last, sp.packed, sp.packed_alt)) return rc;
         if (!last) std::swap(sp.packed, sp.packed_alt);
     }
     s->logical[3] = acc_logical_dtype(s);
@@ -838,6 +878,7 @@ int nb_destroy(nb_sim *s)
         if (p) (void)hipFree(p);
     if (s->prof_init)
         for (int i = 0; i < PROF_RING; ++i) { (void)hipEventDestroy(s->ev_start[i]); (void)hipEventDestroy(s->ev_stop[i]); }
+    if (s->chunk_graph_exec) (void)hipGraphExecDestroy(s->chunk_graph_exec);
     for (hipEvent_t e : {s->ev_ready, s->ev_done, s->ev_force[0], s->ev_force[1], s->ev_force[2], s->ev_force[3]})
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {s->fstream2, s->cstream, s->stream})

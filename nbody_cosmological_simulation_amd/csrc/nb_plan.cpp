@@ -24,6 +24,9 @@ NbKnobs nb_read_knobs()
     k.tail_pieces = env_int("NB_SYM_TAIL", 0);
     if (k.tail_pieces != 2 && k.tail_pieces != 4 && k.tail_pieces != 8 && k.tail_pieces != 16) k.tail_pieces = 0;
     k.chunks = std::min(4, std::max(0, env_int("NB_CHUNKS", 0)));
+    k.chunk_graph = env_int("NB_CHUNK_GRAPH", 1) != 0;
+    k.chunk_serial = env_int("NB_CHUNK_SERIAL", 0) != 0;
+    k.chunk_prio = env_int("NB_CHUNK_PRIO", 0) != 0;
     k.r_onesided = env_int("NB_R", 0);
     k.no_prune = getenv("NB_NO_PRUNE") != nullptr;
     k.no_pe_sym = getenv("NB_NO_PE_SYM") != nullptr;

@@ -19,6 +19,8 @@ struct NbKnobs {
     int sym_split = 0;     // NB_SYM_SPLIT: cut EVERY sweep into 1 / 2 / 4 / 8 pieces; 0 = tail smoothing only
     int tail_pieces = 0;   // NB_SYM_TAIL: pieces per sweep of the tail-smoothed super-rows (4 or 8); 0 = auto
     int chunks = 0;        // NB_CHUNKS: pipeline chunks of the multi-GPU step (1..4); 0 = by work
+    bool chunk_serial = false, chunk_prio = false;   // experiments: NB_CHUNK_SERIAL (all force chunks on one stream), NB_CHUNK_PRIO (stream priorities)
+    bool chunk_graph = true;   // NB_CHUNK_GRAPH=0: enqueue the chunked steps eagerly instead of replaying a captured hipGraph
     int r_onesided = 0;    // NB_R: targets per thread of the one-sided fp64 kernel
     bool no_prune = false;   // NB_NO_PRUNE: all-pairs max-r2 scan at any N
     bool no_pe_sym = false;  // NB_NO_PE_SYM: one-sided potential-energy kernel
