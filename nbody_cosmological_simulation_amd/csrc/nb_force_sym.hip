@@ -302,7 +302,7 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                     } else {
                         // FLOAT32 hook: the 1-ulp v_rsq_f32 cubed, no Newton correction (round 2).  Measured against the
                         // exact fp64 forces at N = 30 000 (tests/tools/f32_accuracy.py, relative to the force scale): the
-                        // reference's own fp32 arithmetic (oracle) max 1.05e-7 / rms 1.51e-8; this kernel WITH the
+                        // reference's own fp32 arithmetic (its CPU restatement) max 1.05e-7 / rms 1.51e-8; this kernel WITH the
                         // first-order correction 1.26e-7 / 1.61e-8, WITHOUT 1.23e-7 / 1.21e-8 -- the error of the summed
                         // forces is set by the fp32 roundings of the differences, r2 and the products, not by the last
                         // ulp of q^-3/2, so the three packed ops of the correction bought nothing (0.657 -> 0.556 ms per

@@ -195,6 +195,11 @@ struct NbMetricsArgs {
                                     // counts[nb], max_radius used
 };
 size_t nb_metrics_scratch_bytes(int n, int num_bins);
+// stable radix sorts of 32- / 64-bit unsigned keys (nb_sort.hip: rocPRIM); values are particle indices
+size_t nb_sort_temp_bytes(int n, int key64);
+hipError_t nb_sort_keys(void *tmp, size_t tmp_bytes, const void *kin, void *kout, int n, int key64, hipStream_t st);
+hipError_t nb_sort_pairs(void *tmp, size_t tmp_bytes, const void *kin, void *kout, const int *vin, int *vout, int n,
+                         int key64, hipStream_t st);
 hipError_t nb_launch_metrics(const NbMetricsArgs &a, hipStream_t st);
 
 // ---- dtype-faithful generic force evaluation (nb_generic.hip) ---------------------------------------------------

@@ -6,13 +6,13 @@
 //                                                                                              metrics.py:98-145
 //   dispersion      unbiased standard deviation of |v|                                         metrics.py:148-156
 //
-// Design: no sort.  The order statistic and the enclosed masses are both "for every i, accumulate over the j whose
-// key is below key_i" -- an all-pairs sweep of two compares and a conditional add per pair, tiled through LDS like
-// the one-sided force kernel (1/7 of a force evaluation's VALU work, 0.1 ms at N = 65 536), deterministic, and
-// without the sort / scan / scatter chain of the reference.  Ties are broken by index.  Bin sums are added in a
-// fixed order (one workgroup per bin), in fp64.  Per-particle arithmetic follows torch op by op in the state's
-// LOGICAL dtype A (fp32 state tensors: fp32 products, sums, sqrt, divide -- no fma), so that bin membership and the
-// escape test take the decisions the reference takes.
+// Design: the two rankings (the percentile radius; the enclosed mass inside every star's r_com) follow the reference's
+// own route -- sort, then a prefix sum -- in O(N log N): a stable radix sort of the radii's bit patterns (nb_sort.hip),
+// a fixed-order three-pass fp64 scan of the masses in r_com order, and one pass of per-star decisions.  (Round 2's
+// first version ranked by an all-pairs sweep: 8.2 ms at N = 65 536, 40 ms at N = 262 144)  Ties
+// keep index order.  Bin sums are added in a fixed order (one workgroup per bin), in fp64.  Per-particle arithmetic
+// follows torch op by op in the state's LOGICAL dtype A (fp32 state tensors: fp32 products, sums, sqrt, divide -- no
+// fma), so that bin membership and the escape test take the decisions the reference takes.
 #include "nb_internal.h"
 
 namespace {
@@ -145,10 +145,26 @@ metrics_finish_sums_kernel(const double *__restrict__ part, int nblocks, int n, 
     }
 }
 
-// K3: distance from the centre of mass
+// Sort keys: radii are >= +0 or NaN, so their bit patterns order like the values; NaN goes last (torch.sort's rule).
+template <typename A> struct KeyOf;
+template <> struct KeyOf<float> {
+    typedef unsigned type;
+    static __device__ __forceinline__ unsigned make(float x) { return x != x ? 0xffffffffu : __float_as_uint(x); }
+    static __device__ __forceinline__ float back(unsigned k) { return __uint_as_float(k); }   // all-ones is a NaN
+};
+template <> struct KeyOf<double> {
+    typedef unsigned long long type;
+    static __device__ __forceinline__ unsigned long long make(double x)
+    { return x != x ? ~0ull : (unsigned long long)__double_as_longlong(x); }
+    static __device__ __forceinline__ double back(unsigned long long k) { return __longlong_as_double((long long)k); }
+};
+
+// K3: distance from the centre of mass; sort keys of r and r_com; identity permutation
 template <typename S, typename A, int D>
 __global__ void __launch_bounds__(MB)
-metrics_rcom_kernel(const S *__restrict__ pos, int n, const double *__restrict__ glob, A *__restrict__ rcom)
+metrics_rcom_kernel(const S *__restrict__ pos, const A *__restrict__ r, int n, const double *__restrict__ glob,
+                    A *__restrict__ rcom, typename KeyOf<A>::type *__restrict__ key_r,
+                    typename KeyOf<A>::type *__restrict__ key_rc, int *__restrict__ idx)
 {
     const int i = blockIdx.x * MB + threadIdx.x;
     if (i >= n) return;
@@ -158,56 +174,89 @@ metrics_rcom_kernel(const S *__restrict__ pos, int n, const double *__restrict__
         const A d = (A)pos[(size_t)i * D + k] - (A)glob[1 + k];
         s = (k == 0) ? d * d : s + d * d;
     }
-    rcom[i] = sqrt_rn<A>(s);
+    const A rc = sqrt_rn<A>(s);
+    rcom[i] = rc;
+    key_r[i] = KeyOf<A>::make(r[i]);
+    key_rc[i] = KeyOf<A>::make(rc);
+    idx[i] = i;
 }
 
-// K4: all-pairs ranking.  For target i: rank_i = #{j : r_j < r_i, ties by index} (order statistic of the radii),
-// enc_i = sum of m_j over {j : rcom_j < rcom_i, ties by index, own mass included} (enclosed mass), then the
-// per-particle decisions: radial bin, bound flag, and the one particle whose rank is `kth` publishes its radius.
+// Enclosed mass = inclusive prefix sum of the masses in r_com order (metrics.py:128-134: argsort, cumsum -- whose CPU
+// kernel accumulates in double and rounds every element to the tensor's dtype).  Three fixed-order passes over
+// blocks of SCAN_EB sorted positions: block totals, their exclusive scan, the in-block scan + per-star decisions.
+constexpr int SCAN_IT = 4, SCAN_EB = MB * SCAN_IT;
+
 template <typename S, typename A>
 __global__ void __launch_bounds__(MB)
-metrics_rank_kernel(const A *__restrict__ r, const A *__restrict__ rcom, const S *__restrict__ mass,
-                    const A *__restrict__ vm, int n, int kth, double G, const float *__restrict__ edges, int num_bins,
-                    int *__restrict__ bin_out, unsigned char *__restrict__ bound_out, double *__restrict__ glob)
+metrics_scan_totals_kernel(const S *__restrict__ mass, const int *__restrict__ order, int n, double *__restrict__ bsum)
 {
-    __shared__ A s_r[MB], s_rc[MB];
-    __shared__ A s_m[MB];
-    const int i = blockIdx.x * MB + threadIdx.x;
-    const bool live = i < n;
-    const A ri = live ? r[i] : (A)0, rci = live ? rcom[i] : (A)0;
-    int rank = 0;
-    double enc = 0.0;
-    for (int j0 = 0; j0 < n; j0 += MB) {
-        const int j = j0 + threadIdx.x;
-        // padding sources never count: +inf keys, zero mass
-        s_r[threadIdx.x] = j < n ? r[j] : (A)__builtin_inf();
-        s_rc[threadIdx.x] = j < n ? rcom[j] : (A)__builtin_inf();
-        s_m[threadIdx.x] = j < n ? (A)mass[j] : (A)0;
+    __shared__ double s_red[MB];
+    const int k0 = blockIdx.x * SCAN_EB + threadIdx.x * SCAN_IT;
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < SCAN_IT; ++q)
+        if (k0 + q < n) t += (double)(A)mass[order[k0 + q]];
+    t = block_sum(t, s_red);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = t;
+}
+
+__global__ void metrics_scan_offsets_kernel(double *__restrict__ bsum, int nblocks)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double run = 0.0;
+    for (int b = 0; b < nblocks; ++b) { const double t = bsum[b]; bsum[b] = run; run += t; }
+}
+
+// K4: star i = order[k] of sorted position k: enclosed mass (own mass included, ties in index order -- the sort is
+// stable), bound flag, radial bin; thread 0 publishes the kth smallest radius.
+template <typename S, typename A>
+__global__ void __launch_bounds__(MB)
+metrics_decide_kernel(const A *__restrict__ r, const A *__restrict__ rcom, const S *__restrict__ mass,
+                      const A *__restrict__ vm, const int *__restrict__ order, const double *__restrict__ boff,
+                      const typename KeyOf<A>::type *__restrict__ key_r_sorted, int n, int kth, double G,
+                      const float *__restrict__ edges, int num_bins, int *__restrict__ bin_out,
+                      unsigned char *__restrict__ bound_out, double *__restrict__ glob)
+{
+    __shared__ double s_scan[MB];
+    const int k0 = blockIdx.x * SCAN_EB + threadIdx.x * SCAN_IT;
+    int who[SCAN_IT];
+    double pre[SCAN_IT], t = 0.0;
+#pragma unroll
+    for (int q = 0; q < SCAN_IT; ++q) {
+        who[q] = k0 + q < n ? order[k0 + q] : -1;
+        if (who[q] >= 0) t += (double)(A)mass[who[q]];
+        pre[q] = t;
+    }
+    // exclusive scan of the thread totals (Hillis-Steele, fixed order)
+    s_scan[threadIdx.x] = t;
+    __syncthreads();
+    for (int st = 1; st < MB; st <<= 1) {
+        const double add = (int)threadIdx.x >= st ? s_scan[threadIdx.x - st] : 0.0;
         __syncthreads();
-#pragma unroll 8
-        for (int jj = 0; jj < MB; ++jj) {
-            const int jg = j0 + jj;
-            const A rj = s_r[jj], rcj = s_rc[jj];
-            rank += (rj < ri || (rj == ri && jg < i)) ? 1 : 0;
-            enc += (rcj < rci || (rcj == rci && jg <= i)) ? (double)s_m[jj] : 0.0;
+        s_scan[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const double base = boff[blockIdx.x] + (s_scan[threadIdx.x] - t);
+    if (blockIdx.x == 0 && threadIdx.x == 0) glob[6] = (double)KeyOf<A>::back(key_r_sorted[kth]);
+    const A g2 = (A)(2.0 * G);            // metrics.py:133: the Python scalar 2*G enters as A
+#pragma unroll
+    for (int q = 0; q < SCAN_IT; ++q) {
+        const int i = who[q];
+        if (i < 0) continue;
+        const A enc = (A)(base + pre[q]);
+        const A rci = rcom[i], ri = r[i];
+        const A rcc = (rci < (A)0.1) ? (A)0.1 : rci;
+        const A vesc = sqrt_rn<A>(div_rn<A>(g2 * enc, rcc));
+        bound_out[i] = (vm[i] < vesc) ? 1 : 0;
+        // bin b holds edge_b <= r < edge_b+1 (metrics.py:65); r is compared in A against the float32 edges
+        int b = -1;
+        if (num_bins > 0) {
+            int c = 0;
+            for (int e = 0; e <= num_bins; ++e) c += ((A)edges[e] <= ri) ? 1 : 0;
+            b = (c >= 1 && c <= num_bins) ? c - 1 : -1;
         }
-        __syncthreads();
+        bin_out[i] = b;
     }
-    if (!live) return;
-    if (rank == kth) glob[6] = (double)ri;
-    // metrics.py:133: sqrt(2 * G * enclosed / r.clamp(min=0.1)) in A; the Python scalar 2*G enters as A
-    const A g2 = (A)(2.0 * G);
-    const A rcc = (rci < (A)0.1) ? (A)0.1 : rci;
-    const A vesc = sqrt_rn<A>(div_rn<A>(g2 * (A)enc, rcc));
-    bound_out[i] = (vm[i] < vesc) ? 1 : 0;
-    // bin b holds edge_b <= r < edge_b+1 (metrics.py:65); r is compared in A against the float32 edges
-    int b = -1;
-    if (num_bins > 0) {
-        int c = 0;
-        for (int e = 0; e <= num_bins; ++e) c += ((A)edges[e] <= ri) ? 1 : 0;
-        b = (c >= 1 && c <= num_bins) ? c - 1 : -1;
-    }
-    bin_out[i] = b;
 }
 
 // K5: block b < num_bins: mean tangential speed and count of bin b; block num_bins: bound count and dispersion.
@@ -258,11 +307,20 @@ hipError_t run(const NbMetricsArgs &a, hipStream_t st)
     auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
     A *r = (A *)take(sizeof(A) * n), *vt = (A *)take(sizeof(A) * n), *vm = (A *)take(sizeof(A) * n);
     A *rcom = (A *)take(sizeof(A) * n);
+    typedef typename KeyOf<A>::type K;
+    K *key_r = (K *)take(sizeof(K) * n), *key_rc = (K *)take(sizeof(K) * n);
+    K *key_r_s = (K *)take(sizeof(K) * n), *key_rc_s = (K *)take(sizeof(K) * n);
+    int *idx = (int *)take(sizeof(int) * n), *order = (int *)take(sizeof(int) * n);
     int *bin = (int *)take(sizeof(int) * n);
     unsigned char *bound = (unsigned char *)take(n);
+    const int sblocks = (n + SCAN_EB - 1) / SCAN_EB;
+    double *bsum = (double *)take(sizeof(double) * (sblocks + 1));
     double *part = (double *)take(sizeof(double) * 8 * M_PART_BLOCKS);
     double *glob = (double *)take(sizeof(double) * 8);
     float *edges = (float *)take(sizeof(float) * (nb + 2));
+    const int key64 = sizeof(K) == 8;
+    const size_t sort_bytes = nb_sort_temp_bytes(n, key64);
+    void *sort_tmp = take(sort_bytes);
     int blocks = (n + MB - 1) / MB;
     const int pblocks = blocks < M_PART_BLOCKS ? blocks : M_PART_BLOCKS;
     hipLaunchKernelGGL((metrics_prep_kernel<S, A, D>), dim3(pblocks), dim3(MB), 0, st, (const S *)a.pos, (const S *)a.vel,
@@ -270,9 +328,17 @@ hipError_t run(const NbMetricsArgs &a, hipStream_t st)
     hipLaunchKernelGGL((metrics_finish_sums_kernel<A>), dim3(1), dim3(MB), 0, st, part, pblocks, n, a.max_radius,
                        a.edges, nb, glob, edges);
     if (!a.radius_only) {
-        hipLaunchKernelGGL((metrics_rcom_kernel<S, A, D>), dim3(blocks), dim3(MB), 0, st, (const S *)a.pos, n, glob, rcom);
-        hipLaunchKernelGGL((metrics_rank_kernel<S, A>), dim3(blocks), dim3(MB), 0, st, r, rcom, (const S *)a.mass, vm, n,
-                           a.kth, a.G, edges, nb, bin, bound, glob);
+        hipLaunchKernelGGL((metrics_rcom_kernel<S, A, D>), dim3(blocks), dim3(MB), 0, st, (const S *)a.pos, r, n, glob, rcom,
+                           key_r, key_rc, idx);
+        hipError_t e = nb_sort_keys(sort_tmp, sort_bytes, key_r, key_r_s, n, key64, st);
+        if (e != hipSuccess) return e;
+        e = nb_sort_pairs(sort_tmp, sort_bytes, key_rc, key_rc_s, idx, order, n, key64, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((metrics_scan_totals_kernel<S, A>), dim3(sblocks), dim3(MB), 0, st, (const S *)a.mass, order, n,
+                           bsum);
+        hipLaunchKernelGGL(metrics_scan_offsets_kernel, dim3(1), dim3(64), 0, st, bsum, sblocks);
+        hipLaunchKernelGGL((metrics_decide_kernel<S, A>), dim3(sblocks), dim3(MB), 0, st, r, rcom, (const S *)a.mass, vm,
+                           order, bsum, key_r_s, n, a.kth, a.G, edges, nb, bin, bound, glob);
     }
     // radius_only: no bins, no particles -> the last block just publishes max r / the max_radius in use
     const int nb_eff = a.radius_only ? 0 : nb, n_eff = a.radius_only ? 0 : n;
@@ -286,11 +352,16 @@ hipError_t run(const NbMetricsArgs &a, hipStream_t st)
 size_t nb_metrics_scratch_bytes(int n, int num_bins)
 {
     const size_t al = 256;
+    auto up = [&](size_t bytes) { return (bytes + al - 1) & ~(al - 1); };
     size_t b = 0;
-    b += 4 * (((size_t)n * 8 + al - 1) & ~(al - 1));
-    b += ((size_t)n * 4 + al - 1) & ~(al - 1);
-    b += ((size_t)n + al - 1) & ~(al - 1);
-    b += 8 * 8 * M_PART_BLOCKS + 256 + ((size_t)(num_bins + 2) * 4 + al - 1);
+    b += 4 * up((size_t)n * 8);                     // r, vt, vm, rcom
+    b += 4 * up((size_t)n * 8);                     // keys and sorted keys of r, r_com
+    b += 3 * up((size_t)n * 4);                     // idx, order, bin
+    b += up((size_t)n);                             // bound
+    b += up(8 * ((size_t)(n + SCAN_EB - 1) / SCAN_EB + 1));
+    b += up(8 * 8 * M_PART_BLOCKS) + up(64) + up((size_t)(num_bins + 2) * 4);
+    const size_t s32 = nb_sort_temp_bytes(n, 0), s64 = nb_sort_temp_bytes(n, 1);
+    b += up(s32 > s64 ? s32 : s64);
     return b + 1024;
 }
 
