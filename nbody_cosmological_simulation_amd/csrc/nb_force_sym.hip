@@ -699,8 +699,17 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
                             const float sq = __fmul_rn(df, df);
                             d2 = (k == 0) ? sq : __fadd_rn(d2, sq);
                         }
+#ifdef NB_PE_F32_EXACT
                         const float dist = __builtin_sqrtf(__fadd_rn(d2, eps2_f));
                         term = (double)__fdiv_rn(mass_prod_f32((float)mi[ri], (float)mj[rj], mass_dt), dist);
+#else
+                        // m_a m_b / sqrt(q) as one v_rsq_f32 and a product (1.5 ulp per term, unbiased) instead of the
+                        // correctly rounded sqrt and divide (about 25 instructions): the terms are summed in fp64 here,
+                        // while the reference's own fp32 .sum() of N^2 terms carries ~1e-7 of rounding -- the last ulp
+                        // of a term is far below what the result can show (measured: DESIGN.md 4.6)
+                        const float y = __builtin_amdgcn_rsqf(__fadd_rn(d2, eps2_f));
+                        term = (double)__fmul_rn(mass_prod_f32((float)mi[ri], (float)mj[rj], mass_dt), y);
+#endif
                     } else {
                         double q = eps2;
 #pragma unroll
