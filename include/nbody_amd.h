@@ -172,7 +172,7 @@ int nb_set_hook_stream(int device, void *hip_stream, int enable);
 
 /* ---- diagnostics --------------------------------------------------------------------- */
 
-/* metrics.py:25-156 on the handle's CURRENT state, on the device (no sort: an all-pairs ranking sweep gives the
+/* metrics.py:25-156 on the handle's CURRENT state, on the device (stable radix sort + fixed-order scan for the
  * order statistic and the enclosed masses):
  *   compute_rotation_curve  -> curve_mean[num_bins] (NaN for empty bins), curve_count[num_bins]
  *   compute_galaxy_radius   -> scalars[1] = sorted(r)[min(int(n * percentile / 100), n - 1)]
