@@ -246,6 +246,20 @@ def main():
     kern_ms, launches = sim.kernel_time()
     kernel_name = sim.force_kernel_name()
     e1 = sim.get_total_energy()
+    collective = None
+    if world > 1 or runtime.force_comm():
+        # what the per-step collective costs on THIS node (both carriers, back-to-back calls on zeroed scratch),
+        # and the invariant of the replicated integration: every rank holds the same bits
+        from nbody_cosmological_simulation_amd import checkpoint
+        collective = {"force_vector_bytes": n * pos.shape[1] * (8 if mode == nb.PrecisionMode.FLOAT64 else 4),
+                      "carrier": runtime.allreduce_label(),
+                      "rccl_us_per_allreduce": sim.allreduce_time("rccl"),
+                      "direct_us_per_allreduce": sim.allreduce_time("direct")}
+        hashes = [checkpoint.state_hash(sim)]
+        if world > 1:
+            hashes = [None] * world
+            dist.all_gather_object(hashes, checkpoint.state_hash(sim))
+        collective["ranks_hold_identical_state"] = len(set(hashes)) == 1
 
     if rank == 0:
         is64 = mode == nb.PrecisionMode.FLOAT64
@@ -274,6 +288,7 @@ def main():
             "config": {"workload": f"N={n} exponential-disk galaxy (seed 42), fp32 ICs, {mode.value} mode, "
                                    f"G=1e-3 eps=0.1 dt=0.01, KDK leapfrog, all-pairs direct sum",
                        "parallelism": runtime.partition_label(world)},
+            "collective": collective,
             "pair_interactions_per_s": float(n) * n * args.steps / elapsed,
             "energy_drift_rel_timed_region": (e1 - e0) / abs(e0),
             "energy_drift_note": "raw drift over the timed steps (after warm-up), for the record only; the metric's "

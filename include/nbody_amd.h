@@ -206,7 +206,40 @@ int nb_metrics_tensors(int device, const void *pos, const void *vel, const void 
 int nb_comm_unique_id(void *id_out, int32_t *id_bytes /* in: capacity, out: size */);
 int nb_comm_init(nb_sim *s, const void *id /* NULL: attach the existing process communicator */, int32_t id_bytes);
 int nb_comm_ready(void);      /* ranks of the process communicator, 0 when there is none */
+int nb_comm_quiesce(void);    /* first half of a shutdown: wait for this process's device work (then: a barrier of the
+                               * host transport, so that no rank frees buffers a peer still reads; then nb_comm_shutdown) */
 int nb_comm_shutdown(void);
+
+/* Direct xGMI all-reduce of small force vectors (csrc/nb_p2p.hip).  The per-step collective at
+ * the benchmark size is 1 MiB between 8 GPUs -- pure latency -- so, next to the RCCL communicator, the ranks of ONE
+ * node can attach a two-hop all-reduce that loads directly from the peers' memory over xGMI (one kernel, rank-ordered
+ * sums: bit-identical on all ranks).  Setup, driven by the host language over its own transport:
+ *   every rank: nb_comm_p2p_export (allocates the shared region; returns its HIP IPC handle)
+ *   all-gather the handles in rank order; every rank: nb_comm_p2p_import(handles, nranks)
+ *   barrier; every rank: nb_comm_p2p_selftest (collective; bounded waits); combine the verdicts (logical AND);
+ *   every rank: nb_comm_p2p_enable(verdict).
+ * Once enabled, nb_step / nb_compute_accelerations use it for force vectors of at most capacity_bytes (fp32: even
+ * element counts), and RCCL for everything else; NB_NO_P2P=1 (read at nb_create) keeps a handle on RCCL.  A peer that
+ * does not arrive within 300 s raises an error at the next nb_synchronize.  nb_comm_shutdown releases the region. */
+int nb_comm_p2p_export(int32_t device, int32_t rank, int32_t nranks, int64_t capacity_bytes, void *handle_out,
+                       int32_t *handle_bytes /* in: capacity (>= 64), out: size */);
+int nb_comm_p2p_import(const void *handles /* nranks handles, rank order */, int32_t nranks);
+int nb_comm_p2p_selftest(int32_t rounds, double timeout_s);
+int nb_comm_p2p_enable(int32_t on);
+int nb_comm_p2p_state(void);  /* 0 none, 1 attached, 2 enabled */
+/* measurement (collective): average microseconds of `iters` back-to-back all-reduces of this handle's force-vector
+ * size on zeroed scratch -- which = 0: RCCL, 1: the direct path -- so a multi-GPU bench can state what its collective
+ * costs on the node it ran on */
+int nb_comm_allreduce_time(nb_sim *s, int32_t which, int32_t iters, double *us_per_call);
+/* tests: the direct all-reduce kernel between `nranks` VIRTUAL ranks inside this process (a one-GPU box can then run
+ * the 8-rank geometry): concurrent = 0 runs the ranks' kernels one after the other with pre-satisfied flags, twice;
+ * concurrent = 1 uses one stream per rank and the real barriers (as many hardware queues as ranks: up to 4),
+ * concurrent = 2 runs all ranks in one dispatch (co-resident by construction, any rank count); both report the time
+ * per all-reduce.  *bad = elements that differ from the closed form (+1e6 per rank whose barrier timed out). */
+int nb_comm_p2p_virtual_test(int32_t device, int32_t nranks, int64_t count, int32_t dtype, int32_t concurrent,
+                             int32_t iters, double timeout_s, int32_t *bad, double *us_per_call);
+/* tests: all-reduce `count` host elements (NB_F32 / NB_F64) in place through the direct path (collective) */
+int nb_comm_p2p_allreduce(void *host_inout, int64_t count, int32_t dtype, double timeout_s);
 
 /* The work plan of the pair-symmetric kernels for one rank, computed WITHOUT a device (pure host code; what
  * nb_set_state uploads).  For tests of the partition: the union over ranks must cover every tile pair once.

@@ -29,7 +29,8 @@ EXPORTS = [
     "nb_set_accelerations", "nb_compute_accelerations", "nb_step", "nb_kick_drift", "nb_kick",
     "nb_energy", "nb_quant_debug", "nb_quant_bins_rows", "nb_quantize_distance_squared", "nb_quantize_force",
     "nb_grid_quantize", "nb_grid_quantize_safe", "nb_comm_unique_id", "nb_comm_init", "nb_comm_ready",
-    "nb_comm_shutdown", "nb_plan_debug", "nb_set_hook_stream", "nb_metrics", "nb_metrics_tensors",
+    "nb_comm_shutdown", "nb_comm_quiesce", "nb_comm_p2p_export", "nb_comm_p2p_import", "nb_comm_p2p_selftest",
+    "nb_comm_p2p_enable", "nb_comm_p2p_state", "nb_comm_p2p_allreduce", "nb_comm_allreduce_time", "nb_comm_p2p_virtual_test", "nb_plan_debug", "nb_set_hook_stream", "nb_metrics", "nb_metrics_tensors",
     "nb_kernel_time", "nb_force_kernel_name", "nb_synchronize", "nb_device_count", "nb_abi_version", "nb_last_error",
 ]
 
@@ -91,6 +92,16 @@ def lib():
                                 C.POINTER(C.c_int64), pdbl], C.c_int),
         "nb_comm_ready": ([], C.c_int),
         "nb_comm_shutdown": ([], C.c_int),
+        "nb_comm_quiesce": ([], C.c_int),
+        "nb_comm_p2p_export": ([C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_int32)], C.c_int),
+        "nb_comm_p2p_import": ([C.c_void_p, C.c_int32], C.c_int),
+        "nb_comm_p2p_selftest": ([C.c_int32, C.c_double], C.c_int),
+        "nb_comm_p2p_enable": ([C.c_int32], C.c_int),
+        "nb_comm_p2p_state": ([], C.c_int),
+        "nb_comm_p2p_allreduce": ([C.c_void_p, C.c_int64, C.c_int32, C.c_double], C.c_int),
+        "nb_comm_allreduce_time": ([C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)], C.c_int),
+        "nb_comm_p2p_virtual_test": ([C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_double)], C.c_int),
         "nb_plan_debug": ([C.POINTER(NbConfig), i32, i32, i32, pi32, pi32, i64, pi32, pi32, pi32, pi32, pi32], C.c_int),
         "nb_kernel_time": ([vp, pdbl, pi32], C.c_int),
         "nb_force_kernel_name": ([vp], C.c_char_p),
@@ -105,6 +116,10 @@ def lib():
         fn.restype = res
     _lib = L
     return L
+
+
+def last_error() -> str:
+    return lib().nb_last_error().decode("utf-8", "replace")
 
 
 def check(rc):

@@ -164,6 +164,7 @@ struct nb_sim {
     double *small_part = nullptr;        // ... INT8 / INT4: per-target min / max of the forces (2 n doubles)
     void *gen_scalars = nullptr;         // generic (dtype-faithful) path: device scalars of one evaluation
     bool last_generic = false;           // the last force evaluation ran on the generic path (no threshold tables)
+    bool used_p2p = false;               // a force vector of this handle went through the direct xGMI all-reduce
     void *metrics_scratch = nullptr;     // nb_metrics work arrays (allocated on first use)
     size_t metrics_cap = 0;
     NbKnobs knobs;                       // environment knobs, read once in nb_create
@@ -191,6 +192,17 @@ bool grid_mode(int mode) { return mode >= NB_INT8_SIM; }
 bool comm_active(const nb_sim *s)
 {
     return (s->cfg.nranks > 1 && !(s->cfg.flags & NB_FLAG_NO_COMM)) || s->comm != nullptr;
+}
+// The direct xGMI all-reduce (nb_p2p.hip) serves this handle's force vector when every rank enabled it after the
+// collective self-test, the process communicator is the one it was built for, and the vector fits its buffers.
+// The decision depends only on values that are equal on all ranks.
+constexpr double P2P_STEP_TIMEOUT_S = 300.0;
+bool p2p_use(const nb_sim *s, int64_t cnt)
+{
+    if (s->knobs.no_p2p || !s->comm || nb_p2p_state() != 2) return false;
+    if (nb_p2p_nranks() != g_pc.nranks || nb_p2p_device() != s->cfg.device) return false;
+    if (!s->is_f64 && (cnt & 1)) return false;                 // the kernel moves 8-byte units
+    return (size_t)cnt * (s->is_f64 ? 8 : 4) <= nb_p2p_capacity();
 }
 int mode_levels(const nb_config &c)
 {
@@ -573,6 +585,10 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
     const bool fuse_kick = do_kick && !multi && !fq;
     const bool want_open = do_kick && open_next && *open_next;   // nb_step asks: may this evaluation open the next step?
     bool opened = false;
+    // multi-GPU: the rank's partial force vector goes straight into the buffer the peers read (direct xGMI
+    // all-reduce), or into `acc` for the in-place RCCL all-reduce
+    const bool p2p = multi && p2p_use(s, cnt);
+    void *red_out = p2p ? nb_p2p_data() : s->acc;
     if (used_sym) {
         const auto &sp = s->sym;
         // uniform-mass kernels leave out the mass factor: G*m in T arithmetic (fp32: (float)G * m)
@@ -581,20 +597,24 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         // inside nb_step the reduction also opens the next step and repacks its positions
         const bool open = fuse_kick && want_open;
         HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.col_upto,
-                                    sp.tile_b, c.n, sp.np, c.dim, s->is_f64, scale, s->acc, s->vel, half_dt,
+                                    sp.tile_b, c.n, sp.np, c.dim, s->is_f64, scale, red_out, s->vel, half_dt,
                                     open ? 2 : (fuse_kick ? 1 : 0), s->pos, sp.packed, c.dt, s->stream));
         opened = open;
     } else {
         // one-sided path inside nb_step: the reduction can also open the next step (one launch fewer per step,
         // which is what small systems are bound by)
         const bool open = fuse_kick && want_open;
-        HIPCHK(nb_launch_reduce(s->partial, s->geom.nchunks, cnt, s->acc, s->is_f64, s->vel, half_dt,
+        HIPCHK(nb_launch_reduce(s->partial, s->geom.nchunks, cnt, red_out, s->is_f64, s->vel, half_dt,
                                 open ? 2 : (fuse_kick ? 1 : 0), s->pos, c.dt, s->stream));
         opened = open;
     }
-    if (multi)
+    if (p2p) {
+        HIPCHK(nb_p2p_allreduce(s->acc, (size_t)cnt, s->is_f64, P2P_STEP_TIMEOUT_S, s->stream));
+        s->used_p2p = true;
+    } else if (multi) {
         NCCLCHK(g_rccl.AllReduce(s->acc, s->acc, (size_t)cnt, s->is_f64 ? ncclDouble : ncclFloat, ncclSum, s->comm,
                                  s->stream));
+    }
     bool kicked = fuse_kick;
     if (fq) {
         // min/max of the summed forces, then quantisation with the closing kick (and, inside nb_step, the next
@@ -1440,6 +1460,206 @@ int nb_comm_init(nb_sim *s, const void *id, int32_t id_bytes)
     return NB_OK;
 }
 
+// ---- direct xGMI all-reduce (nb_p2p.hip): setup is driven by the host language, which owns the transport ----
+int nb_comm_p2p_export(int32_t device, int32_t rank, int32_t nranks, int64_t capacity_bytes, void *handle_out,
+                       int32_t *handle_bytes)
+{
+    if (!handle_out || !handle_bytes) return fail(NB_ERR_INVALID, "null argument");
+    if (*handle_bytes < (int32_t)nb_p2p_handle_bytes())
+        return fail(NB_ERR_INVALID, "handle buffer too small (need %zu)", nb_p2p_handle_bytes());
+    if (capacity_bytes < 8) return fail(NB_ERR_INVALID, "capacity must be positive");
+    if (int rc = check_device(device)) return rc;
+    DeviceGuard guard(device);
+    std::lock_guard<std::mutex> lock(g_pc_mu);
+    HIPCHK(nb_p2p_export(device, rank, nranks, (size_t)capacity_bytes, handle_out));
+    *handle_bytes = (int32_t)nb_p2p_handle_bytes();
+    return NB_OK;
+}
+
+int nb_comm_p2p_import(const void *handles, int32_t nranks)
+{
+    if (!handles) return fail(NB_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lock(g_pc_mu);
+    if (nb_p2p_device() < 0) return fail(NB_ERR_COMM, "nb_comm_p2p_export has not run in this process");
+    DeviceGuard guard(nb_p2p_device());
+    HIPCHK(nb_p2p_import(handles));
+    if (nb_p2p_nranks() != nranks) return fail(NB_ERR_INVALID, "%d handles for %d ranks", nranks, nb_p2p_nranks());
+    return NB_OK;
+}
+
+// Collective.  Integer-valued patterns (exact sums in any order) of several lengths, both element types, against the
+// closed form; short timeout.  Returns NB_OK only if every element of every round was right on THIS rank; the
+// caller combines the ranks' verdicts over its own transport and calls nb_comm_p2p_enable with the result.
+int nb_comm_p2p_selftest(int32_t rounds, double timeout_s)
+{
+    std::lock_guard<std::mutex> lock(g_pc_mu);
+    if (nb_p2p_state() < 1) return fail(NB_ERR_COMM, "direct all-reduce not attached");
+    DeviceGuard guard(nb_p2p_device());
+    const size_t cap = nb_p2p_capacity();
+    void *scratch = nullptr;
+    int *bad = nullptr;
+    HIPCHK(hipMalloc(&scratch, cap));
+    if (hipMalloc((void **)&bad, sizeof(int)) != hipSuccess) { (void)hipFree(scratch); return fail(NB_ERR_HIP, "hipMalloc"); }
+    int rc = NB_OK, host_bad = 0, status = 0;
+    hipError_t e = hipMemset(bad, 0, sizeof(int));
+    const int P = nb_p2p_nranks();
+    const size_t lengths[5] = {2, 14, (size_t)(510 * P + 6), 131072, cap / 8};
+    for (int r = 0; r < rounds && e == hipSuccess; ++r)
+        for (int f64 = 0; f64 < 2 && e == hipSuccess; ++f64)
+            for (int k = 0; k < 5 && e == hipSuccess; ++k) {
+                size_t count = lengths[k];
+                if (count * 8 > cap) count = cap / 8;
+                if (!f64) count *= 2;                       // same bytes
+                e = nb_p2p_selftest_round(scratch, count, f64, r * 10 + k, timeout_s, bad, nullptr);
+            }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(&host_bad, bad, sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = nb_p2p_status(&status);
+    (void)hipFree(scratch);
+    (void)hipFree(bad);
+    if (e != hipSuccess) rc = fail(NB_ERR_HIP, "direct all-reduce self-test: %s", hipGetErrorString(e));
+    else if (status) rc = fail(NB_ERR_COMM, "direct all-reduce self-test: a peer did not arrive within %.1f s", timeout_s);
+    else if (host_bad) rc = fail(NB_ERR_COMM, "direct all-reduce self-test: %d wrong elements", host_bad);
+    return rc;
+}
+
+int nb_comm_p2p_enable(int32_t on)
+{
+    std::lock_guard<std::mutex> lock(g_pc_mu);
+    nb_p2p_enable(on != 0);
+    return NB_OK;
+}
+
+int nb_comm_p2p_state(void)
+{
+    std::lock_guard<std::mutex> lock(g_pc_mu);
+    return nb_p2p_state();
+}
+
+// Collective, for tests: all-reduce `count` host elements (NB_F32 / NB_F64) through the direct path, result back
+// in place.  Works without an RCCL communicator.
+int nb_comm_p2p_allreduce(void *host_inout, int64_t count, int32_t dtype, double timeout_s)
+{
+    if (!host_inout || count < 1) return fail(NB_ERR_INVALID, "bad argument");
+    if (dtype != NB_F32 && dtype != NB_F64) return fail(NB_ERR_INVALID, "dtype must be NB_F32 or NB_F64");
+    std::lock_guard<std::mutex> lock(g_pc_mu);
+    if (nb_p2p_state() < 1) return fail(NB_ERR_COMM, "direct all-reduce not attached");
+    const size_t bytes = (size_t)count * (dtype == NB_F64 ? 8 : 4);
+    if (bytes > nb_p2p_capacity() || (dtype == NB_F32 && (count & 1)))
+        return fail(NB_ERR_INVALID, "count does not fit the direct all-reduce (capacity %zu bytes, fp32 counts even)",
+                    nb_p2p_capacity());
+    DeviceGuard guard(nb_p2p_device());
+    void *dst = nullptr;
+    HIPCHK(hipMalloc(&dst, bytes));
+    hipError_t e = hipMemcpy(nb_p2p_data(), host_inout, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = nb_p2p_allreduce(dst, (size_t)count, dtype == NB_F64, timeout_s, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(host_inout, dst, bytes, hipMemcpyDeviceToHost);
+    int status = 0;
+    if (e == hipSuccess) e = nb_p2p_status(&status);
+    (void)hipFree(dst);
+    if (e != hipSuccess) return fail(NB_ERR_HIP, "direct all-reduce: %s", hipGetErrorString(e));
+    if (status) return fail(NB_ERR_COMM, "direct all-reduce: a peer did not arrive within %.1f s", timeout_s);
+    return NB_OK;
+}
+
+// Collective, measurement only: average time of `iters` back-to-back all-reduces of this handle's force-vector size
+// (which = 0: RCCL, 1: the direct path) on zeroed scratch, HIP events on the handle's stream.
+int nb_comm_allreduce_time(nb_sim *s, int32_t which, int32_t iters, double *us_per_call)
+{
+    if (!us_per_call || iters < 1) return fail(NB_ERR_INVALID, "bad argument");
+    if (!s) {
+        // no handle (tests of the direct path without an RCCL communicator): 1 MiB of doubles on the NULL stream
+        if (which != 1 || nb_p2p_state() < 1) return fail(NB_ERR_COMM, "without a handle only the attached direct path can be timed");
+        DeviceGuard guard(nb_p2p_device());
+        const size_t cnt = std::min<size_t>(131072, nb_p2p_capacity() / 8);
+        void *buf = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        HIPCHK(hipMalloc(&buf, cnt * 8));
+        hipError_t e = hipMemset(nb_p2p_data(), 0, cnt * 8);
+        if (e == hipSuccess) e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
+            e = hipEventRecord(e0, nullptr);
+            for (int i = 0; i < (pass == 0 ? 10 : iters) && e == hipSuccess; ++i)
+                e = nb_p2p_allreduce(buf, cnt, 1, 30.0, nullptr);
+            if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipFree(buf);
+        if (e != hipSuccess) return fail(NB_ERR_HIP, "all-reduce timing: %s", hipGetErrorString(e));
+        *us_per_call = 1e3 * ms / iters;
+        return NB_OK;
+    }
+    if (!s->comm) return fail(NB_ERR_COMM, "the handle has no communicator");
+    DeviceGuard guard(s->cfg.device);
+    const int64_t cnt = nd(s);
+    const size_t bytes = (size_t)cnt * (s->is_f64 ? 8 : 4);
+    if (which == 1) {
+        if (nb_p2p_state() != 2 || bytes > nb_p2p_capacity() || (!s->is_f64 && (cnt & 1)))
+            return fail(NB_ERR_COMM, "the direct all-reduce is not enabled for this vector");
+    }
+    void *buf = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipMalloc(&buf, bytes));
+    hipError_t e = hipMemsetAsync(buf, 0, bytes, s->stream);
+    if (e == hipSuccess && which == 1) e = hipMemsetAsync(nb_p2p_data(), 0, bytes, s->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    ncclResult_t nr = ncclSuccess;
+    for (int pass = 0; pass < 2 && e == hipSuccess && nr == ncclSuccess; ++pass) {       // pass 0 warms up
+        const int reps = pass == 0 ? 10 : iters;
+        e = hipEventRecord(e0, s->stream);
+        for (int i = 0; i < reps && e == hipSuccess && nr == ncclSuccess; ++i) {
+            if (which == 1) e = nb_p2p_allreduce(buf, (size_t)cnt, s->is_f64, P2P_STEP_TIMEOUT_S, s->stream);
+            else nr = g_rccl.AllReduce(buf, buf, (size_t)cnt, s->is_f64 ? ncclDouble : ncclFloat, ncclSum, s->comm, s->stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(e1, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    }
+    float ms = 0.0f;
+    if (e == hipSuccess && nr == ncclSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    if (nr != ncclSuccess) return fail(NB_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(nr) : "?");
+    if (e != hipSuccess) return fail(NB_ERR_HIP, "all-reduce timing: %s", hipGetErrorString(e));
+    *us_per_call = 1e3 * ms / iters;
+    return NB_OK;
+}
+
+// Tests: the direct all-reduce kernel between `nranks` VIRTUAL ranks of this one process (own regions, own streams),
+// integer patterns against the closed form; see nb_p2p.hip.  *bad = wrong elements (+1e6 per timed-out rank).
+int nb_comm_p2p_virtual_test(int32_t device, int32_t nranks, int64_t count, int32_t dtype, int32_t concurrent, int32_t iters,
+                             double timeout_s, int32_t *bad, double *us_per_call)
+{
+    if (!bad || count < 1 || (dtype != NB_F32 && dtype != NB_F64)) return fail(NB_ERR_INVALID, "bad argument");
+    if (int rc = check_device(device)) return rc;
+    DeviceGuard guard(device);
+    int b = 0;
+    double us = 0.0;
+    HIPCHK(nb_p2p_virtual(nranks, (size_t)count, dtype == NB_F64, concurrent, iters, timeout_s, &b, &us));
+    *bad = b;
+    if (us_per_call) *us_per_call = us;
+    return NB_OK;
+}
+
+// First half of a shutdown: wait for this device's work.  The host language then runs a barrier of its own (no rank
+// may free buffers a peer's kernel still reads) and calls nb_comm_shutdown.
+int nb_comm_quiesce(void)
+{
+    std::lock_guard<std::mutex> lock(g_pc_mu);
+    const int dev = g_pc.comm ? g_pc.device : nb_p2p_device();
+    if (dev < 0) return NB_OK;
+    DeviceGuard guard(dev);
+    HIPCHK(hipDeviceSynchronize());
+    return NB_OK;
+}
+
 int nb_comm_ready(void)
 {
     std::lock_guard<std::mutex> lock(g_pc_mu);
@@ -1449,6 +1669,11 @@ int nb_comm_ready(void)
 int nb_comm_shutdown(void)
 {
     std::lock_guard<std::mutex> lock(g_pc_mu);
+    if (nb_p2p_device() >= 0) {
+        DeviceGuard guard(nb_p2p_device());
+        (void)hipDeviceSynchronize();
+        nb_p2p_shutdown();
+    }
     if (!g_pc.comm) return NB_OK;
     DeviceGuard guard(g_pc.device);
     (void)hipDeviceSynchronize();
@@ -1518,6 +1743,12 @@ int nb_synchronize(nb_sim *s)
     if (!s) return fail(NB_ERR_INVALID, "null handle");
     DeviceGuard guard(s->cfg.device);
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->used_p2p) {
+        int st = 0;
+        HIPCHK(nb_p2p_status(&st));
+        if (st) return fail(NB_ERR_COMM, "direct xGMI all-reduce: a peer did not arrive within %.0f s (results invalid)",
+                            P2P_STEP_TIMEOUT_S);
+    }
     return NB_OK;
 }
 

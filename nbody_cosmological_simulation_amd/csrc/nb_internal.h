@@ -202,6 +202,24 @@ hipError_t nb_sort_pairs(void *tmp, size_t tmp_bytes, const void *kin, void *kou
                          int key64, hipStream_t st);
 hipError_t nb_launch_metrics(const NbMetricsArgs &a, hipStream_t st);
 
+// ---- direct xGMI all-reduce of small force vectors (nb_p2p.hip) ------------------------------------------------
+size_t nb_p2p_handle_bytes();
+hipError_t nb_p2p_export(int device, int rank, int nranks, size_t cap_bytes, void *handle_out);
+hipError_t nb_p2p_import(const void *handles);
+int nb_p2p_state();                 // 0 none, 1 attached, 2 enabled
+void nb_p2p_enable(bool on);
+size_t nb_p2p_capacity();           // bytes of the shared input buffer (0: not attached)
+void *nb_p2p_data();                // this rank's shared input buffer (device pointer)
+int nb_p2p_nranks();
+int nb_p2p_device();
+hipError_t nb_p2p_allreduce(void *dst, size_t count, int is_f64, double timeout_s, hipStream_t st);
+hipError_t nb_p2p_status(int *status);
+hipError_t nb_p2p_selftest_round(void *scratch, size_t count, int is_f64, int round, double timeout_s, int *bad_dev,
+                                 hipStream_t st);
+void nb_p2p_shutdown();
+hipError_t nb_p2p_virtual(int nranks, size_t count, int is_f64, int concurrent, int iters, double timeout_s, int *bad_total,
+                          double *us_per_call);
+
 // ---- dtype-faithful generic force evaluation (nb_generic.hip) ---------------------------------------------------
 size_t nb_generic_scalars_bytes();
 hipError_t nb_launch_generic_r2max(const void *pos, int storage_f64, int n, int dim, int P, double eps2_py, void *sc,

@@ -29,6 +29,7 @@ struct NbKnobs {
     int small_max = 0;       // NB_SMALL_MAX: largest N of the single-launch step (0 = default), NB_SMALL_LANES: lanes per target
     int small_lanes = 0;
     bool no_grid_fast = false;   // NB_NO_GRID_FAST: grid modes always read their tables (A/B of the table-free pair path)
+    bool no_p2p = false;         // NB_NO_P2P: force vectors always go through RCCL (never the direct xGMI all-reduce)
 };
 NbKnobs nb_read_knobs();
 

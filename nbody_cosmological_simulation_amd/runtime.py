@@ -71,12 +71,86 @@ def attach_communicator(handle):
         return
     uid = exchange_unique_id()
     N.check(L.nb_comm_init(handle, uid, len(uid)))
+    if os.environ.get("NB_NO_P2P") is None:
+        attach_direct_allreduce(_ctx["device"] if _ctx["device"] is not None else default_hip_device(),
+                                L.nb_comm_ready(), _ctx["rank"] if L.nb_comm_ready() > 1 else 0)
+
+
+P2P_CAPACITY_BYTES = 4 << 20      # force vectors up to N*D = 524 288 doubles; longer ones are bandwidth-bound: RCCL
+_p2p_log = {"state": "not attempted"}
+
+
+def _all_gather(obj, world):
+    """All ranks' objects in rank order over torch.distributed (the only transport this package uses)."""
+    if world <= 1:
+        return [obj]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, obj, group=_ctx["group"])
+    return out
+
+
+def _node_identity() -> str:
+    try:
+        with open("/proc/sys/kernel/random/boot_id") as f:
+            return f.read().strip()
+    except OSError:
+        import socket
+        return socket.gethostname()
+
+
+def attach_direct_allreduce(device: int, world: int, rank: int, capacity_bytes: int = P2P_CAPACITY_BYTES,
+                            rounds: int = 2, timeout_s: float = 5.0) -> bool:
+    """Set up the direct xGMI all-reduce of libnbody_amd (include/nbody_amd.h, nb_comm_p2p_*) between the ranks of
+    one node: export / all-gather / import of the HIP IPC handles, a collective self-test, and a unanimous vote.
+    Any failure on any rank leaves every rank on RCCL.  Collective; returns whether the direct path is enabled."""
+    L = N.lib()
+    if L.nb_comm_p2p_state() != 0:
+        return L.nb_comm_p2p_state() == 2
+    if world > 8:
+        _p2p_log["state"] = "more than 8 ranks"
+        return False
+    handle = C.create_string_buffer(128)
+    size = C.c_int32(128)
+    rc = L.nb_comm_p2p_export(device, rank, world, capacity_bytes, handle, C.byref(size))
+    mine = {"ok": rc == 0, "node": _node_identity(), "handle": bytes(handle.raw[: size.value]) if rc == 0 else b"",
+            "err": "" if rc == 0 else N.last_error()}
+    everyone = _all_gather(mine, world)
+    ok = all(e["ok"] for e in everyone) and len({e["node"] for e in everyone}) == 1
+    if ok:
+        blob = b"".join(e["handle"] for e in everyone)
+        ok = L.nb_comm_p2p_import(blob, world) == 0
+    # every rank must take the same branch from here on: vote before the self-test (which waits on the peers)
+    ok = all(_all_gather(bool(ok), world))
+    if ok:
+        ok = L.nb_comm_p2p_selftest(rounds, timeout_s) == 0
+        ok = all(_all_gather(bool(ok), world))
+    if not ok:
+        errs = [e["err"] for e in everyone if e["err"]] or [N.last_error()]
+        _p2p_log["state"] = "disabled: " + errs[0]
+    else:
+        _p2p_log["state"] = "enabled"
+    N.check(L.nb_comm_p2p_enable(1 if ok else 0))
+    return bool(ok)
+
+
+def allreduce_label() -> str:
+    """Which collective carries the force vectors (bench.py / logs)."""
+    L = N.lib()
+    if L.nb_comm_ready() <= 0:
+        return "none"
+    return "direct xGMI loads (nb_p2p) + RCCL" if L.nb_comm_p2p_state() == 2 else f"RCCL ({_p2p_log['state']})"
 
 
 def shutdown():
     """Destroy the process communicator (collective).  Call on every rank after the last step and before
     torch.distributed is torn down; simulations created afterwards would need a new communicator."""
-    N.check(N.lib().nb_comm_shutdown())
+    L = N.lib()
+    N.check(L.nb_comm_quiesce())
+    if _dist_ready() and _ctx["world"] > 1:
+        import torch.distributed as dist
+        dist.barrier(group=_ctx["group"])       # no rank frees the shared buffers while a peer's kernel reads them
+    N.check(L.nb_comm_shutdown())
 
 
 def rank_world():

@@ -356,6 +356,13 @@ class GalaxySimulation:
         N.check(N.lib().nb_kernel_time(self._handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def allreduce_time(self, which: str = "rccl", iters: int = 200):
+        """Average microseconds of one all-reduce of this simulation's force vector on the node it runs on
+        ("rccl" or "direct"; collective, measurement only).  None when that path is not available."""
+        us = C.c_double(0.0)
+        rc = N.lib().nb_comm_allreduce_time(self._handle, 1 if which == "direct" else 0, int(iters), C.byref(us))
+        return us.value if rc == 0 else None
+
     def force_kernel_name(self) -> str:
         """Kernel the last force evaluation launched (matches the rocprofv3 kernel-trace rows)."""
         return N.lib().nb_force_kernel_name(self._handle).decode()

@@ -429,16 +429,23 @@ base = {m: run(m) for m in modes}
 os.environ["NBODY_FORCE_COMM"] = "1"
 runtime.init_distributed(device=0)
 assert _native.lib().nb_comm_ready() == 0
-for chunks in ("1", "2", "3", "4"):
-    os.environ["NB_CHUNKS"] = chunks
+for chunks in ("1", "1-rccl", "2", "3", "4"):
+    os.environ["NB_CHUNKS"] = chunks[0]
+    if chunks == "1-rccl":
+        os.environ["NB_NO_P2P"] = "1"                  # read when a simulation is created: force vectors through RCCL
     for m, (p0, v0, e0) in base.items():
         p1, v1, e1 = run(m)
         assert np.array_equal(p0, p1), (m, chunks)
         assert np.array_equal(v0, v1), (m, chunks)
         assert e0 == e1, (m, chunks)
+    os.environ.pop("NB_NO_P2P", None)
     assert _native.lib().nb_comm_ready() == 1          # one communicator for all of them
+    # ... and beside it the direct all-reduce (1 rank: its kernel just moves the vector), which the unchunked
+    # step uses by default
+    assert _native.lib().nb_comm_p2p_state() == 2, runtime._p2p_log
+    assert runtime.allreduce_label().startswith("direct")
 runtime.shutdown()
-assert _native.lib().nb_comm_ready() == 0
+assert _native.lib().nb_comm_ready() == 0 and _native.lib().nb_comm_p2p_state() == 0
 print("RCCL-1RANK-OK")
 '''
     env = dict(os.environ, NB_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -1589,6 +1596,68 @@ if rank == 0:
         tol = 1e-12 if name == "f64" else (2e-6 if name == "f32" else 1e-4)
         assert a["relerr"] < tol, (name, a["relerr"])
         assert abs(a["energy"][0] - a["energy"][1]) <= max(tol, 1e-12) * abs(a["energy"][0]) * (1 if name != "int4" and name != "int4_big" else 100)
+
+
+def test_direct_allreduce_virtual_ranks():
+    """The direct all-reduce kernel with the geometry of a full node on ONE GPU: 1..8 virtual ranks inside one process
+    (own shared regions and streams).  Sequential mode checks the slice / portion arithmetic for every rank count
+    and ragged lengths; the whole-node mode runs the real epoch barriers between 2..8 ranks in one dispatch (co-resident
+    by construction), 1 MiB to 4 MiB, ten rounds each; two ranks also as two dispatches on two streams.  (This test
+    is what exposed that hipDeviceMallocUncached regions return stale data on this stack -- nb_p2p.hip.)"""
+    import subprocess
+    import sys
+    script = r'''
+import os, sys, ctypes as C
+sys.path.insert(0, os.environ["NB_ROOT"])
+from nbody_cosmological_simulation_amd import _native as N
+L = N.lib()
+bad, us = C.c_int32(0), C.c_double(0.0)
+for P in (1, 2, 3, 5, 7, 8):
+    for dt, counts in ((N.NB_F64, (1, 63, 64 * P + 1, 4099, 131072)), (N.NB_F32, (2, 130, 8198, 262144))):
+        for count in counts:
+            N.check(L.nb_comm_p2p_virtual_test(0, P, count, dt, 0, 2, 0.5, C.byref(bad), C.byref(us)))
+            assert bad.value == 0, ("sequential", P, dt, count, bad.value)
+print("sequential ok", flush=True)
+lat = {}
+for P in (2, 3, 4, 5, 8):
+    # the whole virtual node in ONE dispatch (blockIdx.y = rank): co-resident by construction, real barriers.  A short
+    # probe first: a barrier that cannot complete shows up as bad >= 1e6 within a second, before anything long is queued
+    N.check(L.nb_comm_p2p_virtual_test(0, P, 4099, N.NB_F64, 2, 1, 0.5, C.byref(bad), None))
+    assert bad.value == 0, ("node probe", P, bad.value)
+    for dt, count in ((N.NB_F64, 131072), (N.NB_F64, 4099), (N.NB_F32, 262144), (N.NB_F64, 524288)):
+        N.check(L.nb_comm_p2p_virtual_test(0, P, count, dt, 2, 10, 0.5, C.byref(bad), C.byref(us)))
+        assert bad.value == 0, ("node", P, dt, count, bad.value)
+        if count == 131072:
+            lat[P] = round(us.value, 1)
+    print("node ok", P, lat, flush=True)
+# one stream (and one dispatch) per rank: two ranks always get distinct hardware queues
+N.check(L.nb_comm_p2p_virtual_test(0, 2, 131072, N.NB_F64, 1, 6, 0.5, C.byref(bad), C.byref(us)))
+assert bad.value == 0, ("streams", bad.value)
+print("P2P-VIRTUAL-OK", lat)
+'''
+    env = dict(os.environ, NB_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert "P2P-VIRTUAL-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+    print(res.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_direct_allreduce_between_processes(nb, world):
+    """The direct all-reduce of the force vectors (csrc/nb_p2p.hip) between `world` PROCESSES sharing this GPU:
+    HIP IPC export / import, the collective self-test, then random vectors of several lengths and both element types,
+    each compared bit for bit with the rank-ordered host sum (tests/tools/p2p_worker.py).  A one-GPU box cannot put
+    xGMI between the ranks; the protocol, the memory ordering across processes and the setup code are the same."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NB_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NBODY_FORCE_COMM", "NB_NO_P2P"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29741 + world),
+                          os.path.join(root, "tests", "tools", "p2p_worker.py")], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0 and f"P2P-OK {world}" in res.stdout, res.stdout[-2000:] + res.stderr[-6000:]
 
 
 @pytest.mark.parametrize("mode", MODES)
