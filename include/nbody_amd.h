@@ -229,7 +229,8 @@ int nb_comm_p2p_enable(int32_t on);
 int nb_comm_p2p_state(void);  /* 0 none, 1 attached, 2 enabled */
 /* measurement (collective): average microseconds of `iters` back-to-back all-reduces of this handle's force-vector
  * size on zeroed scratch -- which = 0: RCCL, 1: the direct path -- so a multi-GPU bench can state what its collective
- * costs on the node it ran on */
+ * costs on the node it ran on.  s = NULL: a 1 MiB vector of doubles on the process communicator / the attached direct
+ * path (what the host language compares before it enables the direct path) */
 int nb_comm_allreduce_time(nb_sim *s, int32_t which, int32_t iters, double *us_per_call);
 /* tests: the direct all-reduce kernel between `nranks` VIRTUAL ranks inside this process (a one-GPU box can then run
  * the 8-rank geometry): concurrent = 0 runs the ranks' kernels one after the other with pre-satisfied flags, twice;

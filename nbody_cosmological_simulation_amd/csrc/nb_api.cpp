@@ -1569,28 +1569,37 @@ int nb_comm_allreduce_time(nb_sim *s, int32_t which, int32_t iters, double *us_p
 {
     if (!us_per_call || iters < 1) return fail(NB_ERR_INVALID, "bad argument");
     if (!s) {
-        // no handle (tests of the direct path without an RCCL communicator): 1 MiB of doubles on the NULL stream
-        if (which != 1 || nb_p2p_state() < 1) return fail(NB_ERR_COMM, "without a handle only the attached direct path can be timed");
-        DeviceGuard guard(nb_p2p_device());
-        const size_t cnt = std::min<size_t>(131072, nb_p2p_capacity() / 8);
+        // no handle: 1 MiB of doubles (the benchmark's force vector) on the NULL stream, through the attached direct
+        // path (which = 1; needs no RCCL communicator) or the process communicator (which = 0).  The host language
+        // uses the pair to decide which carrier is faster on this node.
+        std::lock_guard<std::mutex> lock(g_pc_mu);
+        if (which == 1 && nb_p2p_state() < 1) return fail(NB_ERR_COMM, "the direct all-reduce is not attached");
+        if (which != 1 && !g_pc.comm) return fail(NB_ERR_COMM, "no process communicator");
+        DeviceGuard guard(which == 1 ? nb_p2p_device() : g_pc.device);
+        const size_t cnt = which == 1 ? std::min<size_t>(131072, nb_p2p_capacity() / 8) : 131072;
         void *buf = nullptr;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         HIPCHK(hipMalloc(&buf, cnt * 8));
-        hipError_t e = hipMemset(nb_p2p_data(), 0, cnt * 8);
+        hipError_t e = hipMemset(buf, 0, cnt * 8);
+        if (e == hipSuccess && which == 1) e = hipMemset(nb_p2p_data(), 0, cnt * 8);
         if (e == hipSuccess) e = hipEventCreate(&e0);
         if (e == hipSuccess) e = hipEventCreate(&e1);
-        for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
+        ncclResult_t nr = ncclSuccess;
+        for (int pass = 0; pass < 2 && e == hipSuccess && nr == ncclSuccess; ++pass) {
             e = hipEventRecord(e0, nullptr);
-            for (int i = 0; i < (pass == 0 ? 10 : iters) && e == hipSuccess; ++i)
-                e = nb_p2p_allreduce(buf, cnt, 1, 30.0, nullptr);
+            for (int i = 0; i < (pass == 0 ? 10 : iters) && e == hipSuccess && nr == ncclSuccess; ++i) {
+                if (which == 1) e = nb_p2p_allreduce(buf, cnt, 1, 30.0, nullptr);
+                else nr = g_rccl.AllReduce(buf, buf, cnt, ncclDouble, ncclSum, g_pc.comm, nullptr);
+            }
             if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
             if (e == hipSuccess) e = hipDeviceSynchronize();
         }
         float ms = 0.0f;
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && nr == ncclSuccess) e = hipEventElapsedTime(&ms, e0, e1);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
         (void)hipFree(buf);
+        if (nr != ncclSuccess) return fail(NB_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(nr) : "?");
         if (e != hipSuccess) return fail(NB_ERR_HIP, "all-reduce timing: %s", hipGetErrorString(e));
         *us_per_call = 1e3 * ms / iters;
         return NB_OK;

@@ -71,9 +71,10 @@ def attach_communicator(handle):
         return
     uid = exchange_unique_id()
     N.check(L.nb_comm_init(handle, uid, len(uid)))
-    if os.environ.get("NB_NO_P2P") is None:
+    if os.environ.get("NB_NO_P2P") is None and os.environ.get("NB_P2P", "auto") != "0":
         attach_direct_allreduce(_ctx["device"] if _ctx["device"] is not None else default_hip_device(),
-                                L.nb_comm_ready(), _ctx["rank"] if L.nb_comm_ready() > 1 else 0)
+                                L.nb_comm_ready(), _ctx["rank"] if L.nb_comm_ready() > 1 else 0,
+                                compare_with_rccl=os.environ.get("NB_P2P", "auto") != "force")
 
 
 P2P_CAPACITY_BYTES = 4 << 20      # force vectors up to N*D = 524 288 doubles; longer ones are bandwidth-bound: RCCL
@@ -100,10 +101,13 @@ def _node_identity() -> str:
 
 
 def attach_direct_allreduce(device: int, world: int, rank: int, capacity_bytes: int = P2P_CAPACITY_BYTES,
-                            rounds: int = 2, timeout_s: float = 5.0) -> bool:
+                            rounds: int = 2, timeout_s: float = 5.0, compare_with_rccl: bool = False) -> bool:
     """Set up the direct xGMI all-reduce of libnbody_amd (include/nbody_amd.h, nb_comm_p2p_*) between the ranks of
     one node: export / all-gather / import of the HIP IPC handles, a collective self-test, and a unanimous vote.
-    Any failure on any rank leaves every rank on RCCL.  Collective; returns whether the direct path is enabled."""
+    Any failure on any rank leaves every rank on RCCL.  compare_with_rccl: both carriers are then timed on a 1 MiB
+    vector (200 back-to-back calls each, slowest rank counts) and the direct path is enabled only if it is the
+    faster one on this node (NB_P2P=force skips the comparison, NB_P2P=0 the whole setup).  Collective; returns
+    whether the direct path is enabled."""
     L = N.lib()
     if L.nb_comm_p2p_state() != 0:
         return L.nb_comm_p2p_state() == 2
@@ -130,6 +134,17 @@ def attach_direct_allreduce(device: int, world: int, rank: int, capacity_bytes: 
         _p2p_log["state"] = "disabled: " + errs[0]
     else:
         _p2p_log["state"] = "enabled"
+        if compare_with_rccl and L.nb_comm_ready() > 0:
+            t = {}
+            for name, which in (("direct", 1), ("rccl", 0)):
+                us = C.c_double(0.0)
+                rc = L.nb_comm_allreduce_time(None, which, 200, C.byref(us))
+                t[name] = max(v if v is not None else float("inf")
+                              for v in _all_gather(us.value if rc == 0 else None, world))
+            _p2p_log.update(direct_us=t["direct"], rccl_us=t["rccl"])
+            ok = t["direct"] < t["rccl"]
+            _p2p_log["state"] = (f"enabled: 1 MiB all-reduce {t['direct']:.1f} us direct vs {t['rccl']:.1f} us RCCL" if ok else
+                                 f"not used: 1 MiB all-reduce {t['direct']:.1f} us direct vs {t['rccl']:.1f} us RCCL")
     N.check(L.nb_comm_p2p_enable(1 if ok else 0))
     return bool(ok)
 
@@ -139,7 +154,9 @@ def allreduce_label() -> str:
     L = N.lib()
     if L.nb_comm_ready() <= 0:
         return "none"
-    return "direct xGMI loads (nb_p2p) + RCCL" if L.nb_comm_p2p_state() == 2 else f"RCCL ({_p2p_log['state']})"
+    if L.nb_comm_p2p_state() == 2:
+        return f"direct xGMI loads (nb_p2p; {_p2p_log['state']}); RCCL for scalars and long vectors"
+    return f"RCCL (direct path {_p2p_log['state']})"
 
 
 def shutdown():
