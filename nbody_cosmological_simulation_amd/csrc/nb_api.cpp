@@ -1504,17 +1504,27 @@ int nb_comm_p2p_selftest(int32_t rounds, double timeout_s)
     hipError_t e = hipMemset(bad, 0, sizeof(int));
     const int P = nb_p2p_nranks();
     const size_t lengths[5] = {2, 14, (size_t)(510 * P + 6), 131072, cap / 8};
-    for (int r = 0; r < rounds && e == hipSuccess; ++r)
-        for (int f64 = 0; f64 < 2 && e == hipSuccess; ++f64)
+    for (int r = 0; r < rounds && e == hipSuccess && !status; ++r)
+        for (int f64 = 0; f64 < 2 && e == hipSuccess && !status; ++f64) {
             for (int k = 0; k < 5 && e == hipSuccess; ++k) {
                 size_t count = lengths[k];
                 if (count * 8 > cap) count = cap / 8;
                 if (!f64) count *= 2;                       // same bytes
                 e = nb_p2p_selftest_round(scratch, count, f64, r * 10 + k, timeout_s, bad, nullptr);
+                // the very first launch alone: if the peers cannot be reached, find out after ONE bounded wait
+                if (r == 0 && f64 == 0 && k == 0 && e == hipSuccess) {
+                    e = hipDeviceSynchronize();
+                    if (e == hipSuccess) e = nb_p2p_status(&status);
+                    if (status) break;
+                }
             }
+            // at most five launches are queued behind a barrier that may time out
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e == hipSuccess && !status) e = nb_p2p_status(&status);
+        }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(&host_bad, bad, sizeof(int), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = nb_p2p_status(&status);
+    if (e == hipSuccess && !status) e = nb_p2p_status(&status);
     (void)hipFree(scratch);
     (void)hipFree(bad);
     if (e != hipSuccess) rc = fail(NB_ERR_HIP, "direct all-reduce self-test: %s", hipGetErrorString(e));

@@ -101,7 +101,7 @@ def _node_identity() -> str:
 
 
 def attach_direct_allreduce(device: int, world: int, rank: int, capacity_bytes: int = P2P_CAPACITY_BYTES,
-                            rounds: int = 2, timeout_s: float = 5.0, compare_with_rccl: bool = False) -> bool:
+                            rounds: int = 2, timeout_s: float = 2.0, compare_with_rccl: bool = False) -> bool:
     """Set up the direct xGMI all-reduce of libnbody_amd (include/nbody_amd.h, nb_comm_p2p_*) between the ranks of
     one node: export / all-gather / import of the HIP IPC handles, a collective self-test, and a unanimous vote.
     Any failure on any rank leaves every rank on RCCL.  compare_with_rccl: both carriers are then timed on a 1 MiB
