@@ -123,6 +123,11 @@ struct ProcComm {
 };
 ProcComm g_pc;
 std::mutex g_pc_mu;
+// The direct all-reduce has ONE shared input buffer per process: a handle on another stream must not fill it while
+// the previous user's kernels may still read it.  Handles alternate rarely (several simulations alive at once), so
+// the hand-over is a host-side wait on the previous user's stream; a single simulation never pays for it.
+hipStream_t g_p2p_last_stream = nullptr;
+std::mutex g_p2p_mu;
 
 constexpr int PROF_RING = 256;
 
@@ -589,6 +594,11 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
     // all-reduce), or into `acc` for the in-place RCCL all-reduce
     const bool p2p = multi && p2p_use(s, cnt);
     void *red_out = p2p ? nb_p2p_data() : s->acc;
+    if (p2p) {
+        std::lock_guard<std::mutex> lock(g_p2p_mu);
+        if (g_p2p_last_stream && g_p2p_last_stream != s->stream) HIPCHK(hipStreamSynchronize(g_p2p_last_stream));
+        g_p2p_last_stream = s->stream;
+    }
     if (used_sym) {
         const auto &sp = s->sym;
         // uniform-mass kernels leave out the mass factor: G*m in T arithmetic (fp32: (float)G * m)
@@ -889,6 +899,10 @@ int nb_destroy(nb_sim *s)
     if (!s) return NB_OK;
     DeviceGuard guard(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    {
+        std::lock_guard<std::mutex> lock(g_p2p_mu);
+        if (g_p2p_last_stream == s->stream) g_p2p_last_stream = nullptr;
+    }
     s->comm = nullptr;              // borrowed from the process (nb_comm_shutdown destroys it)
     for (void *p : {s->pos, s->vel, s->mass, s->acc, (void *)s->partial, s->staging, (void *)s->tab,
                     (void *)s->scratch, (void *)s->scalars, (void *)s->fbins, (void *)s->sym.work,

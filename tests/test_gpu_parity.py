@@ -445,6 +445,16 @@ for chunks in ("1", "1-rccl", "2", "3", "4"):
     # step uses by default
     assert _native.lib().nb_comm_p2p_state() == 2, runtime._p2p_log
     assert runtime.allreduce_label().startswith("direct")
+# two simulations alive at once share the ONE input buffer of the direct path: interleaved steps stay bit-identical
+os.environ["NB_CHUNKS"] = "1"
+a = nb.GalaxySimulation(pos, vel, mass, precision_mode=nb.PrecisionMode.FLOAT64)
+b = nb.GalaxySimulation(pos, vel, mass, precision_mode=nb.PrecisionMode.FLOAT32)
+for k in (3, 2):
+    a.run(k); b.run(k)
+for sim, m in ((a, nb.PrecisionMode.FLOAT64), (b, nb.PrecisionMode.FLOAT32)):
+    assert np.array_equal(sim.positions.numpy(), base[m][0]), m
+    assert np.array_equal(sim.velocities.numpy(), base[m][1]), m
+a.close(); b.close()
 runtime.shutdown()
 assert _native.lib().nb_comm_ready() == 0 and _native.lib().nb_comm_p2p_state() == 0
 print("RCCL-1RANK-OK")
