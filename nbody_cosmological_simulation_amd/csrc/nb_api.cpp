@@ -618,14 +618,26 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
                                 open ? 2 : (fuse_kick ? 1 : 0), s->pos, c.dt, s->stream));
         opened = open;
     }
+    bool kicked = fuse_kick;
     if (p2p) {
-        HIPCHK(nb_p2p_allreduce(s->acc, (size_t)cnt, s->is_f64, P2P_STEP_TIMEOUT_S, s->stream));
+        // every rank holds every summed element inside this kernel: the kicks (and, inside nb_step, the next step's
+        // opening kick + drift + repack) ride along as they do in the single-GPU reduction -- no pack launch
+        NbP2PKick kk{};
+        if (do_kick && !fq && !s->knobs.no_p2p_kick) {
+            const bool open = want_open;
+            kk.mode = open ? 2 : 1;
+            kk.dim = c.dim; kk.np = used_sym ? s->sym.np : 0;
+            kk.vel = s->vel; kk.pos = s->pos; kk.packed = used_sym ? (void *)s->sym.packed : nullptr;
+            kk.half_dt = half_dt; kk.dt = c.dt;
+            kicked = true;
+            opened = open;
+        }
+        HIPCHK(nb_p2p_allreduce(s->acc, (size_t)cnt, s->is_f64, P2P_STEP_TIMEOUT_S, s->stream, &kk));
         s->used_p2p = true;
     } else if (multi) {
         NCCLCHK(g_rccl.AllReduce(s->acc, s->acc, (size_t)cnt, s->is_f64 ? ncclDouble : ncclFloat, ncclSum, s->comm,
                                  s->stream));
     }
-    bool kicked = fuse_kick;
     if (fq) {
         // min/max of the summed forces, then quantisation with the closing kick (and, inside nb_step, the next
         // step's opening kick + drift) in the same launch

@@ -212,7 +212,14 @@ size_t nb_p2p_capacity();           // bytes of the shared input buffer (0: not 
 void *nb_p2p_data();                // this rank's shared input buffer (device pointer)
 int nb_p2p_nranks();
 int nb_p2p_device();
-hipError_t nb_p2p_allreduce(void *dst, size_t count, int is_f64, double timeout_s, hipStream_t st);
+// leapfrog work fused behind the sum: mode 1 closing half kick, 2 + the next step's opening kick + drift (+ repack)
+struct NbP2PKick {
+    int mode, dim, np;
+    void *vel, *pos, *packed;      // storage type of the force vector; packed may be null (one-sided kernels)
+    double half_dt, dt;
+};
+hipError_t nb_p2p_allreduce(void *dst, size_t count, int is_f64, double timeout_s, hipStream_t st,
+                            const NbP2PKick *kick = nullptr);
 hipError_t nb_p2p_status(int *status);
 hipError_t nb_p2p_selftest_round(void *scratch, size_t count, int is_f64, int round, double timeout_s, int *bad_dev,
                                  hipStream_t st);

@@ -19,6 +19,7 @@
 //
 // This is an accelerator for small vectors only: the RCCL communicator stays, serves every other collective (scalars,
 // large vectors) and is the fallback when the self-test of this path (nb_api.cpp) does not pass on every rank.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,11 +34,12 @@ namespace {
 #define P2P_ACQ 0
 #endif
 constexpr int P2P_MAX_RANKS = 8;
-constexpr int P2P_BLOCKS = 64;
+constexpr int P2P_MAX_BLOCKS = 256;       // workgroups per all-reduce: NB_P2P_BLOCKS (same on every rank), default 256 --
+                                          // every rank touches all N*D elements, and the work is pure latency
 constexpr int P2P_THREADS = 256;
-constexpr int P2P_BATCH = 4;              // units a thread has in flight per peer
-constexpr size_t P2P_SIG_BYTES = 16384;       // 2 phases x 64 blocks x 8 ranks x 8 B = 8 KiB of flags, then the status word
-constexpr size_t P2P_STATUS_OFF = 12288;
+constexpr int P2P_BATCH = 2;              // units a thread has in flight per peer
+constexpr size_t P2P_SIG_BYTES = 40960;   // 2 phases x 256 blocks x 8 ranks x 8 B = 32 KiB of flags, then the status word
+constexpr size_t P2P_STATUS_OFF = 32768;
 typedef unsigned long long u64;
 
 struct P2PArgs {
@@ -47,6 +49,11 @@ struct P2PArgs {
     long long units;            // 8-byte units (one double / two floats)
     long long timeout_ticks;    // of wall_clock64()
     size_t data_off, out_off;
+    // leapfrog work fused behind the sum (what reduce_sym_kernel fuses on one GPU): 0 none, 1 closing half kick,
+    // 2 closing kick + the next step's opening kick + drift (+ repack of the pair-symmetric kernel's positions)
+    int kick, dim, np;
+    void *vel, *pos, *packed;
+    double half_dt, dt;
 };
 
 struct P2PState {
@@ -57,8 +64,16 @@ struct P2PState {
     char *base[P2P_MAX_RANKS] = {};
     u64 epoch = 0;
     double ticks_per_s = 1e8;
+    int blocks = P2P_MAX_BLOCKS;
 };
 P2PState g;
+
+int p2p_env_blocks()
+{
+    const char *v = getenv("NB_P2P_BLOCKS");
+    const int b = v ? atoi(v) : P2P_MAX_BLOCKS;
+    return b < 1 ? 1 : (b > P2P_MAX_BLOCKS ? P2P_MAX_BLOCKS : b);
+}
 
 // The shared region is ORDINARY device memory (hipMalloc).  Measured on MI355X / ROCm 7.2 with the virtual-node test
 // below: regions from hipExtMallocWithFlags(hipDeviceMallocUncached) returned stale data to the very next kernel
@@ -96,7 +111,7 @@ __device__ __forceinline__ void p2p_barrier(const P2PArgs &a, int phase)
     __syncthreads();
     const int t = threadIdx.x;
     if (t < a.nranks) {
-        const size_t slot = ((size_t)phase * P2P_BLOCKS + blockIdx.x) * P2P_MAX_RANKS;
+        const size_t slot = ((size_t)phase * P2P_MAX_BLOCKS + blockIdx.x) * P2P_MAX_RANKS;
         u64 *mine_at_peer = (u64 *)a.base[t] + slot + a.rank;
         __hip_atomic_store(mine_at_peer, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const u64 *peer_at_mine = (const u64 *)a.base[a.rank] + slot + t;
@@ -120,12 +135,53 @@ template <bool F64> __device__ __forceinline__ u64 add_units(u64 x, u64 y)
     return (u64)__float_as_uint(lo) | ((u64)__float_as_uint(hi) << 32);
 }
 
+// One summed element (index e of the (N, D) force vector, value f): store it and apply the kicks / drift in the
+// storage type with torch's separate multiply and add roundings (simulation.py:132-141), exactly as the single-GPU
+// reduction does.
+template <typename T>
+__device__ __forceinline__ void p2p_leapfrog(const P2PArgs &a, long long e, T f)
+{
+    T *vel = (T *)a.vel;
+    T v = vel[e];
+    const T h = (T)a.half_dt;
+    if (sizeof(T) == 8) v = (T)__dadd_rn((double)v, __dmul_rn((double)f, (double)h));
+    else v = (T)__fadd_rn((float)v, __fmul_rn((float)f, (float)h));
+    if (a.kick == 2) {
+        T *pos = (T *)a.pos;
+        T x;
+        if (sizeof(T) == 8) {
+            v = (T)__dadd_rn((double)v, __dmul_rn((double)f, (double)h));
+            x = (T)__dadd_rn((double)pos[e], __dmul_rn((double)v, a.dt));
+        } else {
+            v = (T)__fadd_rn((float)v, __fmul_rn((float)f, (float)h));
+            x = (T)__fadd_rn((float)pos[e], __fmul_rn((float)v, (float)a.dt));
+        }
+        pos[e] = x;
+        if (a.packed) ((T *)a.packed)[(size_t)(e % a.dim) * a.np + e / a.dim] = x;
+    }
+    vel[e] = v;
+}
+
+template <bool F64>
+__device__ __forceinline__ void p2p_finish(const P2PArgs &a, u64 *__restrict__ dst, long long u, u64 s)
+{
+    dst[u] = s;
+    if (a.kick) {
+        if (F64) {
+            p2p_leapfrog<double>(a, u, __longlong_as_double((long long)s));
+        } else {
+            p2p_leapfrog<float>(a, 2 * u, __uint_as_float((unsigned)s));
+            p2p_leapfrog<float>(a, 2 * u + 1, __uint_as_float((unsigned)(s >> 32)));
+        }
+    }
+}
+
 template <bool F64>
 __device__ __forceinline__ void p2p_body(const P2PArgs &a, u64 *__restrict__ dst)
 {
     const int P = a.nranks, t = threadIdx.x;
     const long long S = (a.units + P - 1) / P;                          // slice of a rank
-    const long long per = (S + P2P_BLOCKS - 1) / P2P_BLOCKS;            // portion of a workgroup
+    const long long per = (S + gridDim.x - 1) / gridDim.x;              // portion of a workgroup
     p2p_barrier(a, 0);
     {
         const long long lo = (long long)a.rank * S + (long long)blockIdx.x * per;
@@ -152,7 +208,7 @@ __device__ __forceinline__ void p2p_body(const P2PArgs &a, u64 *__restrict__ dst
                 for (int q = 1; q < P2P_MAX_RANKS; ++q)
                     if (q < P) s = add_units<F64>(s, v[k][q]);
                 store_sys(a.base[a.rank] + a.out_off + (size_t)u * 8, s);
-                dst[u] = s;
+                p2p_finish<F64>(a, dst, u, s);
             }
         }
     }
@@ -194,7 +250,7 @@ __device__ __forceinline__ void p2p_body(const P2PArgs &a, u64 *__restrict__ dst
         for (int k = 0; k < P2P_BATCH; ++k)
 #pragma unroll
             for (int q = 0; q < P2P_MAX_RANKS; ++q)
-                if (at[k][q] >= 0) dst[at[k][q]] = v[k][q];
+                if (at[k][q] >= 0) p2p_finish<F64>(a, dst, at[k][q], v[k][q]);
     }
 }
 
@@ -262,6 +318,15 @@ __global__ void p2p_check_kernel(const u64 *res, long long units, int nranks, in
 
 size_t nb_p2p_handle_bytes() { return sizeof(hipIpcMemHandle_t); }
 
+static void p2p_set_kick(P2PArgs &a, const NbP2PKick *k)
+{
+    a.kick = 0; a.dim = 1; a.np = 0; a.vel = a.pos = a.packed = nullptr; a.half_dt = a.dt = 0.0;
+    if (k && k->mode) {
+        a.kick = k->mode; a.dim = k->dim; a.np = k->np; a.vel = k->vel; a.pos = k->pos; a.packed = k->packed;
+        a.half_dt = k->half_dt; a.dt = k->dt;
+    }
+}
+
 // Allocate this process's shared region and describe it for the peers.
 hipError_t nb_p2p_export(int device, int rank, int nranks, size_t cap_bytes, void *handle_out)
 {
@@ -283,6 +348,7 @@ hipError_t nb_p2p_export(int device, int rank, int nranks, size_t cap_bytes, voi
     g.local = (char *)p;
     g.device = device; g.rank = rank; g.nranks = nranks; g.cap = cap_bytes;
     g.epoch = 0;
+    g.blocks = p2p_env_blocks();
     return hipSuccess;
 }
 
@@ -316,7 +382,7 @@ int nb_p2p_device() { return g.device; }
 
 // dst <- sum over ranks of their data buffers (count elements of double / float).  Collective: every rank issues the
 // same sequence of calls.  `dst` is ordinary device memory of this rank.
-hipError_t nb_p2p_allreduce(void *dst, size_t count, int is_f64, double timeout_s, hipStream_t st)
+hipError_t nb_p2p_allreduce(void *dst, size_t count, int is_f64, double timeout_s, hipStream_t st, const NbP2PKick *kick)
 {
     if (!g.attached) return hipErrorNotInitialized;
     const size_t bytes = count * (is_f64 ? 8 : 4);
@@ -328,8 +394,9 @@ hipError_t nb_p2p_allreduce(void *dst, size_t count, int is_f64, double timeout_
     a.units = (long long)((bytes + 7) / 8);
     a.timeout_ticks = (long long)(timeout_s * g.ticks_per_s);
     a.data_off = P2P_SIG_BYTES; a.out_off = P2P_SIG_BYTES + g.cap;
-    if (is_f64) hipLaunchKernelGGL(p2p_allreduce_kernel<true>, dim3(P2P_BLOCKS), dim3(P2P_THREADS), 0, st, a, (u64 *)dst);
-    else hipLaunchKernelGGL(p2p_allreduce_kernel<false>, dim3(P2P_BLOCKS), dim3(P2P_THREADS), 0, st, a, (u64 *)dst);
+    p2p_set_kick(a, kick);
+    if (is_f64) hipLaunchKernelGGL(p2p_allreduce_kernel<true>, dim3(g.blocks), dim3(P2P_THREADS), 0, st, a, (u64 *)dst);
+    else hipLaunchKernelGGL(p2p_allreduce_kernel<false>, dim3(g.blocks), dim3(P2P_THREADS), 0, st, a, (u64 *)dst);
     return hipGetLastError();
 }
 
@@ -403,6 +470,14 @@ hipError_t nb_p2p_virtual(int nranks, size_t count, int is_f64, int concurrent, 
             ticks = 1e3 * khz;
     }
     u64 epoch = 0;
+    // workgroups per rank: the production count, but a whole virtual node in one dispatch must be co-resident
+    // (the kernel needs <= 128 VGPRs: 4 workgroups per CU)
+    int vblocks = p2p_env_blocks();
+    if (concurrent == 2) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            vblocks = std::min(vblocks, std::max(1, 2 * cus / nranks));
+    }
     // concurrent = 2: the whole virtual node in one dispatch
     auto launch_node = [&](hipStream_t s) {
         P2PArgs a;
@@ -411,8 +486,9 @@ hipError_t nb_p2p_virtual(int nranks, size_t count, int is_f64, int concurrent, 
         a.rank = 0; a.nranks = nranks; a.epoch = epoch; a.units = units;
         a.timeout_ticks = (long long)(timeout_s * ticks);
         a.data_off = P2P_SIG_BYTES; a.out_off = P2P_SIG_BYTES + cap;
-        if (is_f64) hipLaunchKernelGGL(p2p_allreduce_node_kernel<true>, dim3(P2P_BLOCKS, nranks), dim3(P2P_THREADS), 0, s, a, d);
-        else hipLaunchKernelGGL(p2p_allreduce_node_kernel<false>, dim3(P2P_BLOCKS, nranks), dim3(P2P_THREADS), 0, s, a, d);
+        p2p_set_kick(a, nullptr);
+        if (is_f64) hipLaunchKernelGGL(p2p_allreduce_node_kernel<true>, dim3(vblocks, nranks), dim3(P2P_THREADS), 0, s, a, d);
+        else hipLaunchKernelGGL(p2p_allreduce_node_kernel<false>, dim3(vblocks, nranks), dim3(P2P_THREADS), 0, s, a, d);
     };
     auto launch = [&](int q, hipStream_t s) {
         P2PArgs a;
@@ -420,8 +496,9 @@ hipError_t nb_p2p_virtual(int nranks, size_t count, int is_f64, int concurrent, 
         a.rank = q; a.nranks = nranks; a.epoch = concurrent ? epoch : 0; a.units = units;      // epoch 0: no barrier ever waits
         a.timeout_ticks = (long long)(timeout_s * ticks);
         a.data_off = P2P_SIG_BYTES; a.out_off = P2P_SIG_BYTES + cap;
-        if (is_f64) hipLaunchKernelGGL(p2p_allreduce_kernel<true>, dim3(P2P_BLOCKS), dim3(P2P_THREADS), 0, s, a, (u64 *)dst[q]);
-        else hipLaunchKernelGGL(p2p_allreduce_kernel<false>, dim3(P2P_BLOCKS), dim3(P2P_THREADS), 0, s, a, (u64 *)dst[q]);
+        p2p_set_kick(a, nullptr);
+        if (is_f64) hipLaunchKernelGGL(p2p_allreduce_kernel<true>, dim3(vblocks), dim3(P2P_THREADS), 0, s, a, (u64 *)dst[q]);
+        else hipLaunchKernelGGL(p2p_allreduce_kernel<false>, dim3(vblocks), dim3(P2P_THREADS), 0, s, a, (u64 *)dst[q]);
     };
     const int fb = (int)((units + 255) / 256);
     for (int it = 0; it < iters && e == hipSuccess; ++it) {
