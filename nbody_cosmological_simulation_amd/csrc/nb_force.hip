@@ -324,19 +324,24 @@ __device__ __forceinline__ unsigned int r2_order_bits(float v)
     return (v != v) ? 0x7fc00000u : __float_as_uint(v);
 }
 
-template <int D, int R>
-__global__ void __launch_bounds__(NB_BLOCK)
-r2max_kernel(const float *__restrict__ pos, ForceGeom g, float eps2, GridTables *__restrict__ tab)
+// all-pairs max of the fp32 r2 over this workgroup's targets and source chunk; thread 0 adds it to tab->r2max_bits
+// SPLIT > 1 (small systems, R = 1): SPLIT neighbouring lanes share a target and deal a tile's sources among them --
+// a thread then walks NB_TJ / SPLIT sources instead of NB_TJ, and there are SPLIT times as many workgroups.
+template <int D, int R, int SPLIT = 1>
+__device__ __forceinline__ void r2max_block(const float *__restrict__ pos, const ForceGeom &g, float eps2,
+                                            GridTables *__restrict__ tab)
 {
+    static_assert(SPLIT == 1 || R == 1, "lane splitting is for one target per thread");
     __shared__ float sj[D][NB_TJ];
     __shared__ unsigned int s_red[NB_BLOCK / 64];
     const int tid = threadIdx.x;
-    const int ibase = blockIdx.x * (NB_BLOCK * R);
+    const int ibase = blockIdx.x * (NB_BLOCK * R / SPLIT);
+    const int sub = tid % SPLIT;
 
     float xi[R][D];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        int i = ibase + r * NB_BLOCK + tid;
+        int i = ibase + r * NB_BLOCK + tid / SPLIT;
         i = i < g.n ? i : g.n - 1;
 #pragma unroll
         for (int k = 0; k < D; ++k) xi[r][k] = pos[(size_t)i * D + k];
@@ -358,7 +363,7 @@ r2max_kernel(const float *__restrict__ pos, ForceGeom g, float eps2, GridTables 
         __syncthreads();
         const int cnt = min(NB_TJ, j_hi - jt);
 #pragma unroll 8
-        for (int jj = 0; jj < cnt; ++jj) {
+        for (int jj = sub; jj < cnt; jj += SPLIT) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float d[D];
@@ -380,6 +385,13 @@ r2max_kernel(const float *__restrict__ pos, ForceGeom g, float eps2, GridTables 
         for (int w = 1; w < NB_BLOCK / 64; ++w) b = max(b, s_red[w]);
         atomicMax(&tab->r2max_bits, b);
     }
+}
+
+template <int D, int R>
+__global__ void __launch_bounds__(NB_BLOCK)
+r2max_kernel(const float *__restrict__ pos, ForceGeom g, float eps2, GridTables *__restrict__ tab)
+{
+    r2max_block<D, R>(pos, g, eps2, tab);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -596,16 +608,32 @@ __device__ __forceinline__ float grid_bin_exact(float t, float min_val, float lm
     return rintf(nrm);   // half-to-even like torch.round
 }
 
+// The same bin for a t within ~1e-5 (relative) of a point c whose fp64 logarithm is known (c = exp(c_log): the result
+// of exp carries the same 1e-16 the library log of t would): log t = c_log + log1p(u), u = (t - c) / c, three terms
+// of the series (u^4 / 4 < 1e-21).  A dozen fp64 operations instead of a library log (~1400 cycles for a lone wave);
+// the threshold search spends all its evaluations inside such a bracket.
+__device__ __forceinline__ float grid_bin_near(float t, double c_log, double c_inv, float lmin, float range, float lm1)
+{
+    const double u = __builtin_fma((double)t, c_inv, -1.0);
+    const double l1p = u * (1.0 + u * (-0.5 + u * (1.0 / 3.0)));
+    const float lt = (float)(c_log + l1p);
+    const float nrm = __fmul_rn(__fdiv_rn(__fsub_rn(lt, lmin), range), lm1);
+    return rintf(nrm);
+}
+
 // One thread per level, NB_LUT_MIN threads per block; the block that arrives last (all others have read
 // tab->r2max_bits and written their entries) writes the scalars and resets the scratch for the next evaluation.
-__global__ void __launch_bounds__(NB_LUT_MIN)
-grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2, float min_val,
-                   PruneState *__restrict__ ps, int allow_fast)
+// FUSED: called by the last workgroup of r2max_tables_kernel (single-block tables, levels <= NB_LUT_MIN; the
+// caller passes the finished maximum).  Otherwise the body of grid_tables_kernel (one workgroup per NB_LUT_MIN levels).
+template <bool FUSED>
+__device__ __forceinline__ void grid_tables_body(GridTables *__restrict__ tab, int levels, float G, float eps2, float min_val,
+                                                 PruneState *__restrict__ ps, int allow_fast, unsigned int r2max_bits)
 {
     __shared__ int s_last;
     __shared__ float s_thr[NB_LUT_MIN], s_lut[NB_LUT_MIN], s_red[NB_LUT_MIN], s_par[4];
-    const int k = blockIdx.x * NB_LUT_MIN + threadIdx.x;
-    const float r2max = __uint_as_float(tab->r2max_bits);
+    const int k = (FUSED ? 0 : blockIdx.x) * NB_LUT_MIN + threadIdx.x;
+    const int tables_blocks = FUSED ? 1 : gridDim.x;
+    const float r2max = __uint_as_float(r2max_bits);
     const float tmin = (eps2 < min_val) ? min_val : eps2;        // diagonal entries: r2 == eps2
     const float tmax = (r2max < min_val) ? min_val : r2max;
     const float lmin = logf_cr(tmin);
@@ -614,17 +642,30 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
     const float lm1 = (float)(levels - 1);
     const bool degenerate = range < 1e-10f || levels > NB_MAX_LUT;
 
-    if (k < levels) {
+    // Small single-block tables (INT4, CUSTOM 64): the value / factor of a level and its threshold are independent
+    // chains of comparable length, so they go to different lanes (threads [0, L) and [128, 128 + L)).
+    const bool two_roles = tables_blocks == 1 && levels <= NB_LUT_MIN / 2;
+    const int tid_l = threadIdx.x;
+    const int ka = two_roles ? (tid_l < levels ? tid_l : -1) : (k < levels ? k : -1);
+    const int kb = two_roles ? ((tid_l >= NB_LUT_MIN / 2 && tid_l - NB_LUT_MIN / 2 < levels) ? tid_l - NB_LUT_MIN / 2 : -1) : ka;
+    const int base_l = two_roles ? 0 : (k - tid_l);          // first level of this workgroup
+    if (ka >= 0) {
         // value of bin k (quantization.py:121-127) and its force factor (simulation.py:97-101)
-        float v = __fdiv_rn((float)k, lm1);
+        float v = __fdiv_rn((float)ka, lm1);
         v = __fmul_rn(v, range);
         v = __fadd_rn(v, lmin);
         float q = (float)exp((double)v);
         q = (q < min_val) ? min_val : q;
-        const float p = (float)pow((double)q, 1.5);
-        tab->qval[k] = q;
-        tab->lut[k] = __fmul_rn(__fdiv_rn(1.0f, p), G);
-
+        // q^1.5 correctly rounded to fp32: q * sqrt(q) in fp64 is good to 2 ulp of fp64, 2^-29 of an fp32 spacing
+        const double qd = (double)q;
+        const float p = (float)(qd * __dsqrt_rn(qd));
+        const float w = __fmul_rn(__fdiv_rn(1.0f, p), G);
+        tab->qval[ka] = q;
+        tab->lut[ka] = w;
+        s_lut[ka - base_l] = w;
+    }
+    if (kb >= 0) {
+        const int k = kb;
         float thr = -__builtin_inff();
         if (k > 0 && !degenerate) {
             if (r2max != r2max) {
@@ -632,37 +673,46 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
             } else {
                 unsigned int lo = __float_as_uint(tmin);   // bin(tmin) == 0 < k
                 unsigned int hi = __float_as_uint(tmax);   // bin(tmax) == L-1 >= k
-                // The edge of bin k sits near exp(lmin + (k - 1/2) range / (L-1)): bracket it within +-1e-5
-                // (a few hundred fp32 values) when both ends check out with the exact formula, so the bisection
-                // needs ~9 instead of ~31 evaluations; otherwise keep the full interval.  The result is the
+                // The edge of bin k sits near exp(lmin + (k - 1/2) range / (L-1)): bracket it within +-4e-6
+                // (~70 fp32 values; the fp32 roundings of the reference's formula move the edge by ~1e-6 at most)
+                // when both ends check out with the exact formula, so the bisection needs ~7 instead of ~31
+                // evaluations; otherwise keep the full interval.  The result is the
                 // same either way (bin is monotone in t).
+                bool near = false;          // both ends of the bracket hold: every further t is within 4e-6 of `edge`
+                double edge = 1.0, edge_log = 0.0, edge_inv = 1.0;
                 if (range > 1e-6f) {
-                    const double edge = exp((double)lmin + ((double)k - 0.5) * (double)range / (double)lm1);
-                    const float a_lo = (float)(edge * (1.0 - 1e-5)), a_hi = (float)(edge * (1.0 + 1e-5));
-                    if (a_lo > tmin && a_lo < tmax && grid_bin_exact(a_lo, min_val, lmin, range, lm1) < (float)k)
-                        lo = __float_as_uint(a_lo);
-                    if (a_hi > tmin && a_hi < tmax && grid_bin_exact(a_hi, min_val, lmin, range, lm1) >= (float)k)
-                        hi = __float_as_uint(a_hi);
+                    edge_log = (double)lmin + ((double)k - 0.5) * (double)range / (double)lm1;
+                    edge = exp(edge_log);
+                    edge_inv = 1.0 / edge;
+                    const float a_lo = (float)(edge * (1.0 - 4e-6)), a_hi = (float)(edge * (1.0 + 4e-6));
+                    const bool in_lo = a_lo > tmin && a_lo < tmax, in_hi = a_hi > tmin && a_hi < tmax;
+                    const bool ok_lo = in_lo && grid_bin_near(a_lo, edge_log, edge_inv, lmin, range, lm1) < (float)k;
+                    const bool ok_hi = in_hi && grid_bin_near(a_hi, edge_log, edge_inv, lmin, range, lm1) >= (float)k;
+                    if (ok_lo) lo = __float_as_uint(a_lo);
+                    if (ok_hi) hi = __float_as_uint(a_hi);
+                    near = ok_lo && ok_hi;
                 }
                 while (hi - lo > 1u) {
                     const unsigned int mid = lo + ((hi - lo) >> 1);
-                    const float b = grid_bin_exact(__uint_as_float(mid), min_val, lmin, range, lm1);
+                    const float b = near ? grid_bin_near(__uint_as_float(mid), edge_log, edge_inv, lmin, range, lm1)
+                                         : grid_bin_exact(__uint_as_float(mid), min_val, lmin, range, lm1);
                     if (b >= (float)k) hi = mid; else lo = mid;
                 }
                 thr = __uint_as_float(hi);
             }
         }
         tab->thr[k] = thr;
-        s_thr[threadIdx.x] = thr;
-        s_lut[threadIdx.x] = tab->lut[k];
+        s_thr[k - base_l] = thr;
     }
     __syncthreads();               // every thread of this block has read tab->r2max_bits and written its entry
-    if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = (atomicAdd(&tab->blocks_done, 1u) == gridDim.x - 1) ? 1 : 0;
+    if (!FUSED) {
+        if (threadIdx.x == 0) {
+            __threadfence();
+            s_last = (atomicAdd(&tab->blocks_done, 1u) == gridDim.x - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_last) return;
     }
-    __syncthreads();
-    if (!s_last) return;
     const bool fin = threadIdx.x == 0;
     // ---- table-free pair path: parameters + validation (single-block tables only: levels <= NB_LUT_MIN) ------
     const double est_a_d = 0.6931471805599453 * (double)lm1 / (double)range;
@@ -670,7 +720,7 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
     const bool est_ok = (range >= 1e-10f && est_a_d < 1.0e4);
     const int kc = levels / 2;
     const float est_bc = (float)(-(double)lmin * (double)lm1 / (double)range - (double)kc);
-    bool fast_try = allow_fast && est_ok && gridDim.x == 1 && levels >= 2 && r2max == r2max && r2max < 1e30f;
+    bool fast_try = allow_fast && est_ok && tables_blocks == 1 && levels >= 2 && r2max == r2max && r2max < 1e30f;
     if (fin) {
         // log2 of the force factor is affine in the bin index: fit it to the table's end points
         const double w0 = (double)s_lut[0], w1 = (double)s_lut[min(levels, NB_LUT_MIN) - 1];
@@ -769,6 +819,37 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
         tab->fast_maxrel = maxrel;
         tab->r2max_bits = 0u;      // consumed (every thread read it on entry): ready for the next atomicMax round
     }
+}
+
+__global__ void __launch_bounds__(NB_LUT_MIN)
+grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2, float min_val,
+                   PruneState *__restrict__ ps, int allow_fast)
+{
+    grid_tables_body<false>(tab, levels, G, eps2, min_val, ps, allow_fast, tab->r2max_bits);
+}
+
+// Small systems (one launch instead of two per grid evaluation): every workgroup adds its part of the all-pairs
+// maximum; the LAST one to arrive (device-scope counter) reads the finished maximum and builds the tables.
+constexpr int NB_R2MAX_SPLIT = 8;
+template <int D, int R>
+__global__ void __launch_bounds__(NB_BLOCK)
+r2max_tables_kernel(const float *__restrict__ pos, ForceGeom g, float eps2, GridTables *__restrict__ tab, int levels,
+                    float G, float min_val, int allow_fast)
+{
+    static_assert(NB_BLOCK == NB_LUT_MIN, "the last workgroup runs the single-block tables code");
+    __shared__ unsigned int s_bits;
+    __shared__ int s_mine;
+    r2max_block<D, R, NB_R2MAX_SPLIT>(pos, g, eps2, tab);
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int total = gridDim.x * gridDim.y;
+        s_mine = (atomicAdd(&tab->blocks_done, 1u) == total - 1) ? 1 : 0;
+        // the maximum itself through the same atomic unit that every workgroup's atomicMax went to
+        s_bits = s_mine ? atomicMax(&tab->r2max_bits, 0u) : 0u;
+    }
+    __syncthreads();
+    if (!s_mine) return;
+    grid_tables_body<true>(tab, levels, G, eps2, min_val, nullptr, allow_fast, s_bits);
 }
 
 // debug / parity: bin index of every pair with the tables the force kernel used
@@ -890,6 +971,31 @@ hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float 
         constexpr int DD = decltype(D)::value;
         if (r == 1) hipLaunchKernelGGL((r2max_kernel<DD, 1>), grid, dim3(NB_BLOCK), 0, st, pos, g, eps2, tab);
         else hipLaunchKernelGGL((r2max_kernel<DD, 4>), grid, dim3(NB_BLOCK), 0, st, pos, g, eps2, tab);
+        return hipGetLastError();
+    });
+}
+
+hipError_t nb_launch_r2max_tables(const float *pos, const ForceGeom &g, int dim, float eps2, GridTables *tab, int levels,
+                                  float G, float min_val, int allow_fast, hipStream_t st)
+{
+    if (levels > NB_LUT_MIN) return hipErrorInvalidValue;
+    const int per_block = NB_BLOCK / NB_R2MAX_SPLIT;
+    const int gx = (g.n + per_block - 1) / per_block;
+    // every workgroup ends in two atomics on one address (they serialise in the L2: ~25 ns each), so about one
+    // workgroup per CU is the right number: fewer, longer source chunks than the force kernels use
+    ForceGeom g2 = g;
+    const int njr = g.j_end - g.j_begin > 0 ? g.j_end - g.j_begin : 1;
+    int nch = 256 / gx;
+    nch = nch < 1 ? 1 : (nch > g.nchunks ? g.nchunks : nch);
+    int chunk = (njr + nch - 1) / nch;
+    chunk = (chunk + NB_TJ - 1) / NB_TJ * NB_TJ;
+    g2.chunk_len = chunk;
+    g2.nchunks = (njr + chunk - 1) / chunk;
+    const dim3 grid(gx, g2.nchunks);
+    return dispatch_dim(dim, [&](auto D) {
+        constexpr int DD = decltype(D)::value;
+        hipLaunchKernelGGL((r2max_tables_kernel<DD, 1>), grid, dim3(NB_BLOCK), 0, st, pos, g2, eps2, tab, levels, G, min_val,
+                           allow_fast);
         return hipGetLastError();
     });
 }

@@ -132,6 +132,9 @@ hipError_t nb_launch_force_f64(const double *pos, const double *mass, double *pa
 hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *partial, const ForceGeom &g,
                                int dim, int hook, int pa, float G, float eps2, const GridTables *tab, int levels,
                                hipStream_t st);
+// small systems: all-pairs maximum and the tables of the evaluation in ONE launch (levels <= NB_LUT_MIN)
+hipError_t nb_launch_r2max_tables(const float *pos, const ForceGeom &g, int dim, float eps2, GridTables *tab, int levels,
+                                  float G, float min_val, int allow_fast, hipStream_t st);
 hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float eps2, GridTables *tab,
                            hipStream_t st);
 // exact max of the fp32 r2 over all pairs via candidate pruning (every rank computes it redundantly,
