@@ -218,6 +218,10 @@ int nb_comm_shutdown(void);
  *   all-gather the handles in rank order; every rank: nb_comm_p2p_import(handles, nranks)
  *   barrier; every rank: nb_comm_p2p_selftest (collective; bounded waits); combine the verdicts (logical AND);
  *   every rank: nb_comm_p2p_enable(verdict).
+ * A handle may also attach WITHOUT any RCCL communicator: when no process communicator exists yet, the direct path is
+ * enabled between exactly the handle's ranks and nb_comm_init gets a NULL id, the process communicator becomes
+ * "direct only" -- every sum (forces, potential energy) takes the direct path, vectors above capacity_bytes are an
+ * error.  (Several ranks may then share one GPU, which RCCL refuses: how the multi-rank step is tested on one GPU.)
  * Once enabled, nb_step / nb_compute_accelerations use it for force vectors of at most capacity_bytes (fp32: even
  * element counts), and RCCL for everything else; NB_NO_P2P=1 (read at nb_create) keeps a handle on RCCL.  A peer that
  * does not arrive within 300 s raises an error at the next nb_synchronize.  nb_comm_shutdown releases the region. */

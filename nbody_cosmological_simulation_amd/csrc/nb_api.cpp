@@ -120,7 +120,11 @@ int load_rccl()
 struct ProcComm {
     ncclComm_t comm = nullptr;
     int nranks = 0, rank = 0, device = -1;
+    // "direct only": no RCCL communicator at all -- every sum goes through the direct all-reduce of nb_p2p.hip
+    // (ranks of one node, vectors up to its capacity).  `comm` then holds a sentinel that is never handed to RCCL.
+    bool direct_only = false;
 };
+char g_direct_sentinel;
 ProcComm g_pc;
 std::mutex g_pc_mu;
 // The direct all-reduce has ONE shared input buffer per process: a handle on another stream must not fill it while
@@ -208,6 +212,29 @@ bool p2p_use(const nb_sim *s, int64_t cnt)
     if (nb_p2p_nranks() != g_pc.nranks || nb_p2p_device() != s->cfg.device) return false;
     if (!s->is_f64 && (cnt & 1)) return false;                 // the kernel moves 8-byte units
     return (size_t)cnt * (s->is_f64 ? 8 : 4) <= nb_p2p_capacity();
+}
+// Sum `count` elements of `buf` over the ranks, in place, on the handle's stream: RCCL, or -- on a direct-only
+// communicator -- a copy into the shared input buffer and the direct all-reduce.
+int comm_allreduce_sum(nb_sim *s, void *buf, size_t count, bool f64)
+{
+    if (!g_pc.direct_only) {
+        NCCLCHK(g_rccl.AllReduce(buf, buf, count, f64 ? ncclDouble : ncclFloat, ncclSum, s->comm, s->stream));
+        return NB_OK;
+    }
+    const size_t bytes = count * (f64 ? 8 : 4);
+    if (nb_p2p_state() != 2 || bytes > nb_p2p_capacity() || (!f64 && (count & 1)))
+        return fail(NB_ERR_COMM, "direct-only communicator: %zu %s elements do not fit the direct all-reduce (capacity %zu "
+                                 "bytes, fp32 counts even); use an RCCL communicator", count, f64 ? "fp64" : "fp32",
+                    nb_p2p_capacity());
+    {
+        std::lock_guard<std::mutex> lock(g_p2p_mu);
+        if (g_p2p_last_stream && g_p2p_last_stream != s->stream) HIPCHK(hipStreamSynchronize(g_p2p_last_stream));
+        g_p2p_last_stream = s->stream;
+    }
+    HIPCHK(hipMemcpyAsync(nb_p2p_data(), buf, bytes, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(nb_p2p_allreduce(buf, count, f64, P2P_STEP_TIMEOUT_S, s->stream));
+    s->used_p2p = true;
+    return NB_OK;
 }
 int mode_levels(const nb_config &c)
 {
@@ -450,7 +477,7 @@ int force_eval_generic(nb_sim *s, bool do_kick, bool *defer_kick, bool *open_nex
     s->last_kernel = "generic_force_kernel";
     s->last_generic = true;
     if (multi)
-        NCCLCHK(g_rccl.AllReduce(s->acc, s->acc, (size_t)cnt, s->is_f64 ? ncclDouble : ncclFloat, ncclSum, s->comm, s->stream));
+        if (int rc = comm_allreduce_sum(s, s->acc, (size_t)cnt, s->is_f64)) return rc;
     if (fq) {
         // quantize_force on a tensor of dtype A (quantization.py:74-88): linear grid over its global min / max
         const bool a64 = (A == NB_F64);
@@ -548,13 +575,14 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
                                               s->prune_state, s->tab, s->stream));
             } else {
                 ForceGeom gmax = s->geom;
-                if (no_comm && c.nranks > 1) {   // a comm-less shard scans every source itself
+                const bool scan_all = (no_comm && c.nranks > 1) || (multi && g_pc.direct_only);
+                if (scan_all) {   // a comm-less shard (and a rank without RCCL's max) scans every source itself
                     gmax.j_begin = 0;
                     gmax.j_end = c.n;
                     gmax.nchunks = (c.n + gmax.chunk_len - 1) / gmax.chunk_len;
                 }
                 HIPCHK(nb_launch_r2max((const float *)s->pos, gmax, c.dim, eps2, s->tab, s->stream));
-                if (multi)   // NB_FLAG_NO_COMM shards see only their own block's maximum
+                if (multi && !scan_all)   // NB_FLAG_NO_COMM shards see only their own block's maximum
                     NCCLCHK(g_rccl.AllReduce(&s->tab->r2max_bits, &s->tab->r2max_bits, 1, ncclUint32, ncclMax, s->comm,
                                              s->stream));
             }
@@ -635,8 +663,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         HIPCHK(nb_p2p_allreduce(s->acc, (size_t)cnt, s->is_f64, P2P_STEP_TIMEOUT_S, s->stream, &kk));
         s->used_p2p = true;
     } else if (multi) {
-        NCCLCHK(g_rccl.AllReduce(s->acc, s->acc, (size_t)cnt, s->is_f64 ? ncclDouble : ncclFloat, ncclSum, s->comm,
-                                 s->stream));
+        if (int rc = comm_allreduce_sum(s, s->acc, (size_t)cnt, s->is_f64)) return rc;
     }
     if (fq) {
         // min/max of the summed forces, then quantisation with the closing kick (and, inside nb_step, the next
@@ -666,7 +693,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
 bool chunked_ok(const nb_sim *s)
 {
     const int sdt = s->is_f64 ? NB_F64 : NB_F32;
-    return s->comm && s->sym.enabled && s->sym.chunk_tile.size() > 2 && s->sym.packed_alt && !grid_mode(s->cfg.mode) &&
+    return s->comm && !g_pc.direct_only && s->sym.enabled && s->sym.chunk_tile.size() > 2 && s->sym.packed_alt && !grid_mode(s->cfg.mode) &&
            s->logical[0] == sdt && s->logical[1] == sdt && s->logical[3] == sdt && s->have_acc;
 }
 
@@ -1117,7 +1144,7 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential)
         }
         if ((c.nranks > 1 && !(c.flags & NB_FLAG_NO_COMM)) || s->comm) {
             if (!s->comm) return fail(NB_ERR_COMM, "nranks > 1 but nb_comm_init was not called");
-            NCCLCHK(g_rccl.AllReduce(s->scalars + 3, s->scalars + 3, 1, ncclDouble, ncclSum, s->comm, s->stream));
+            if (int rc = comm_allreduce_sum(s, s->scalars + 3, 1, true)) return rc;
         }
     }
     HIPCHK(hipMemcpyAsync(host, s->scalars + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
@@ -1471,6 +1498,14 @@ int nb_comm_init(nb_sim *s, const void *id, int32_t id_bytes)
     const int want_n = (s->cfg.flags & NB_FLAG_SHARD_TIMING) ? 1 : s->cfg.nranks;
     const int want_r = (s->cfg.flags & NB_FLAG_SHARD_TIMING) ? 0 : s->cfg.rank;
     std::lock_guard<std::mutex> lock(g_pc_mu);
+    if (!g_pc.comm && !id && nb_p2p_state() == 2 && nb_p2p_nranks() == want_n && nb_p2p_device() == s->cfg.device) {
+        // no unique id but an enabled direct all-reduce between exactly these ranks: a direct-only communicator
+        g_pc.comm = (ncclComm_t)&g_direct_sentinel;
+        g_pc.direct_only = true;
+        g_pc.nranks = want_n;
+        g_pc.rank = want_r;
+        g_pc.device = s->cfg.device;
+    }
     if (!g_pc.comm) {
         if (!id) return fail(NB_ERR_COMM, "no process communicator yet: the first nb_comm_init needs a unique id");
         if (id_bytes != (int32_t)sizeof(ncclUniqueId)) return fail(NB_ERR_INVALID, "bad id size %d", id_bytes);
@@ -1617,7 +1652,7 @@ int nb_comm_allreduce_time(nb_sim *s, int32_t which, int32_t iters, double *us_p
         // uses the pair to decide which carrier is faster on this node.
         std::lock_guard<std::mutex> lock(g_pc_mu);
         if (which == 1 && nb_p2p_state() < 1) return fail(NB_ERR_COMM, "the direct all-reduce is not attached");
-        if (which != 1 && !g_pc.comm) return fail(NB_ERR_COMM, "no process communicator");
+        if (which != 1 && (!g_pc.comm || g_pc.direct_only)) return fail(NB_ERR_COMM, "no RCCL communicator");
         DeviceGuard guard(which == 1 ? nb_p2p_device() : g_pc.device);
         const size_t cnt = which == 1 ? std::min<size_t>(131072, nb_p2p_capacity() / 8) : 131072;
         void *buf = nullptr;
@@ -1648,6 +1683,7 @@ int nb_comm_allreduce_time(nb_sim *s, int32_t which, int32_t iters, double *us_p
         return NB_OK;
     }
     if (!s->comm) return fail(NB_ERR_COMM, "the handle has no communicator");
+    if (which != 1 && g_pc.direct_only) return fail(NB_ERR_COMM, "no RCCL communicator");
     DeviceGuard guard(s->cfg.device);
     const int64_t cnt = nd(s);
     const size_t bytes = (size_t)cnt * (s->is_f64 ? 8 : 4);
@@ -1730,8 +1766,9 @@ int nb_comm_shutdown(void)
     DeviceGuard guard(g_pc.device);
     (void)hipDeviceSynchronize();
     ncclComm_t comm = g_pc.comm;
+    const bool direct_only = g_pc.direct_only;
     g_pc = ProcComm();
-    if (g_rccl.CommDestroy) NCCLCHK(g_rccl.CommDestroy(comm));
+    if (!direct_only && g_rccl.CommDestroy) NCCLCHK(g_rccl.CommDestroy(comm));
     return NB_OK;
 }
 

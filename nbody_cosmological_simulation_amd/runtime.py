@@ -69,6 +69,16 @@ def attach_communicator(handle):
     if L.nb_comm_ready() > 0:
         N.check(L.nb_comm_init(handle, None, 0))
         return
+    if os.environ.get("NB_COMM") == "direct":
+        # no RCCL at all: the ranks of one node (also several processes sharing one GPU, which RCCL refuses) sum
+        # everything through the direct all-reduce; vectors above its capacity are an error
+        world = _ctx["world"] if _dist_ready() else 1
+        ok = attach_direct_allreduce(_ctx["device"] if _ctx["device"] is not None else default_hip_device(), world,
+                                     _ctx["rank"] if world > 1 else 0)
+        if not ok:
+            raise RuntimeError("NB_COMM=direct, but the direct all-reduce could not be set up: " + _p2p_log["state"])
+        N.check(L.nb_comm_init(handle, None, 0))
+        return
     uid = exchange_unique_id()
     N.check(L.nb_comm_init(handle, uid, len(uid)))
     if os.environ.get("NB_NO_P2P") is None and os.environ.get("NB_P2P", "auto") != "0":
@@ -154,6 +164,8 @@ def allreduce_label() -> str:
     L = N.lib()
     if L.nb_comm_ready() <= 0:
         return "none"
+    if L.nb_comm_p2p_state() == 2 and os.environ.get("NB_COMM") == "direct":
+        return "direct loads only (nb_p2p; no RCCL communicator)"
     if L.nb_comm_p2p_state() == 2:
         return f"direct xGMI loads (nb_p2p; {_p2p_log['state']}); RCCL for scalars and long vectors"
     return f"RCCL (direct path {_p2p_log['state']})"

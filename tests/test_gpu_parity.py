@@ -1671,6 +1671,42 @@ def test_direct_allreduce_between_processes(nb, world):
     assert res.returncode == 0 and f"P2P-OK {world}" in res.stdout, res.stdout[-2000:] + res.stderr[-6000:]
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_product_path_on_one_gpu(nb, world, tmp_path):
+    """The REAL multi-rank step on a one-GPU box: `world` processes share the GPU, each is one rank of the engine
+    (nb_create with nranks = world: its own snake-dealt work plan, deferred kicks, force quantisation after the sum,
+    potential-energy sum) and the direct all-reduce carries every sum (NB_COMM=direct -- RCCL refuses several ranks
+    on one GPU).  FLOAT64 <= 1e-12 of the single-GPU trajectory after five steps, the fp32 family 2e-6, grid modes
+    within their bin-flip bands; every rank ends with bit-identical state."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outp = str(tmp_path / "multirank.json")
+    env = dict(os.environ, NB_ROOT=root, NB_OUT=outp, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NBODY_FORCE_COMM", "NB_NO_P2P", "NB_P2P", "NB_COMM"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29761 + world),
+                          os.path.join(root, "tests", "tools", "multirank_worker.py")], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0 and f"MULTIRANK-OK {world}" in res.stdout, res.stdout[-2000:] + res.stderr[-6000:]
+    got = json.load(open(outp))
+    assert got["label"].startswith("direct loads only")
+    ranks = got["ranks"]
+    assert len(ranks) == world
+    for name, tol_x, tol_v in (("f64", 1e-12, 1e-11), ("f64_onesided", 1e-12, 1e-11), ("f32", 2e-6, 2e-5),
+                               ("f16", 2e-6, 2e-5), ("int4", 1e-4, 5e-2), ("int8_big", 1e-4, 5e-2)):
+        a = ranks[0][name]
+        for r in ranks[1:]:
+            assert r[name]["hash"] == a["hash"], f"{name}: ranks hold different states"
+        assert a["relerr_x"] < tol_x and a["relerr_v"] < tol_v, (name, a)
+        etol = 1e-12 if name.startswith("f64") else (2e-6 if name in ("f32", "f16") else 1e-3)
+        assert abs(a["energy"][0] - a["energy"][1]) <= etol * abs(a["energy"][0]), (name, a["energy"])
+    assert ranks[0]["f64"]["kernel"].startswith("force_sym_kernel<double")
+    assert ranks[0]["f64_onesided"]["kernel"].startswith("force_f64")
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("n,d,unequal", [(1, 2, False), (65, 2, True), (1000, 3, False), (3000, 2, True), (4096, 2, False)])
 def test_small_system_single_launch_step_vs_oracle(nb, monkeypatch, n, d, unequal, mode):
