@@ -198,9 +198,17 @@ def main():
         return 0 if args.gpus == world else 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # rehearsal of the multi-rank code path on a ONE-GPU box (tests only): all ranks on device 0, gloo as torch's
+    # transport and the engine's direct-only communicator (RCCL / NCCL refuse several ranks per GPU)
+    rehearsal = os.environ.get("NB_BENCH_ONE_GPU_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
+        os.environ["NB_COMM"] = "direct"
     torch.cuda.set_device(local_rank)
     launched = "RANK" in os.environ          # under torch.distributed.run, also with one rank
-    if launched:
+    if launched and rehearsal:
+        dist.init_process_group(backend="gloo")
+    elif launched:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -240,7 +248,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms, launches = sim.kernel_time()
