@@ -174,6 +174,7 @@ struct nb_sim {
     void *gen_scalars = nullptr;         // generic (dtype-faithful) path: device scalars of one evaluation
     bool last_generic = false;           // the last force evaluation ran on the generic path (no threshold tables)
     bool used_p2p = false;               // a force vector of this handle went through the direct xGMI all-reduce
+    double *sums64 = nullptr;            // multi-GPU, fp32 state, RCCL carrier: the fp64 sums the ranks exchange
     void *metrics_scratch = nullptr;     // nb_metrics work arrays (allocated on first use)
     size_t metrics_cap = 0;
     NbKnobs knobs;                       // environment knobs, read once in nb_create
@@ -618,10 +619,23 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
     const bool fuse_kick = do_kick && !multi && !fq;
     const bool want_open = do_kick && open_next && *open_next;   // nb_step asks: may this evaluation open the next step?
     bool opened = false;
+    double x64_scale = 1.0;
     // multi-GPU: the rank's partial force vector goes straight into the buffer the peers read (direct xGMI
     // all-reduce), or into `acc` for the in-place RCCL all-reduce
-    const bool p2p = multi && p2p_use(s, cnt);
+    // multi-GPU INT8 / INT4 on the pair-symmetric path: the ranks exchange the UNROUNDED fp64 sums and round once,
+    // (float)(sum * scale), exactly where the single-GPU reduction rounds, so the all-reduce itself adds no fp32
+    // rounding of its own before quantize_force snaps the forces to their grid (a last-bit difference there is what
+    // flips a force bin: measured against the single-GPU run after five steps at N = 9000 INT8, two ranks: positions
+    // 1.2e-8 with the fp64 exchange, 1.2e-6 -- a flipped bin -- with fp32 partials).  Twice the bytes, so only where a
+    // grid follows: the other fp32 modes differ across rank counts at the 1e-7 of their in-kernel fp32 running sums
+    // either way (measured: identical with both exchanges).
+    const bool x64 = multi && used_sym && !s->is_f64 && fq && !s->knobs.no_x64;
+    bool p2p = multi && (x64 ? (s->comm && !s->knobs.no_p2p && nb_p2p_state() == 2 && nb_p2p_nranks() == g_pc.nranks &&
+                               nb_p2p_device() == c.device && (size_t)cnt * 8 <= nb_p2p_capacity())
+                             : p2p_use(s, cnt));
     void *red_out = p2p ? nb_p2p_data() : s->acc;
+    if (x64 && !p2p && !s->sums64) HIPCHK(hipMalloc((void **)&s->sums64, (size_t)cnt * sizeof(double)));
+    double *sums64 = x64 ? (p2p ? (double *)nb_p2p_data() : s->sums64) : nullptr;
     if (p2p) {
         std::lock_guard<std::mutex> lock(g_p2p_mu);
         if (g_p2p_last_stream && g_p2p_last_stream != s->stream) HIPCHK(hipStreamSynchronize(g_p2p_last_stream));
@@ -636,7 +650,8 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         const bool open = fuse_kick && want_open;
         HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.col_upto,
                                     sp.tile_b, c.n, sp.np, c.dim, s->is_f64, scale, red_out, s->vel, half_dt,
-                                    open ? 2 : (fuse_kick ? 1 : 0), s->pos, sp.packed, c.dt, s->stream));
+                                    open ? 2 : (fuse_kick ? 1 : 0), s->pos, sp.packed, c.dt, s->stream, 0, -1, sums64));
+        x64_scale = scale;
         opened = open;
     } else {
         // one-sided path inside nb_step: the reduction can also open the next step (one launch fewer per step,
@@ -651,6 +666,8 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
         // every rank holds every summed element inside this kernel: the kicks (and, inside nb_step, the next step's
         // opening kick + drift + repack) ride along as they do in the single-GPU reduction -- no pack launch
         NbP2PKick kk{};
+        kk.f64_to_f32 = x64 ? 1 : 0;
+        kk.scale = x64_scale;
         if (do_kick && !fq && !s->knobs.no_p2p_kick) {
             const bool open = want_open;
             kk.mode = open ? 2 : 1;
@@ -660,8 +677,16 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
             kicked = true;
             opened = open;
         }
-        HIPCHK(nb_p2p_allreduce(s->acc, (size_t)cnt, s->is_f64, P2P_STEP_TIMEOUT_S, s->stream, &kk));
+        HIPCHK(nb_p2p_allreduce(s->acc, (size_t)cnt, s->is_f64 || x64, P2P_STEP_TIMEOUT_S, s->stream, &kk));
         s->used_p2p = true;
+    } else if (multi && x64) {
+        if (int rc = comm_allreduce_sum(s, s->sums64, (size_t)cnt, true)) return rc;
+        const bool fin_kick = do_kick && !fq;
+        const bool open = fin_kick && want_open;
+        HIPCHK(nb_launch_finish_sums64(s->sums64, x64_scale, (float *)s->acc, (float *)s->vel, (float *)s->pos,
+                                       (float *)s->sym.packed, c.n, s->sym.np, c.dim, fin_kick ? (open ? 2 : 1) : 0,
+                                       half_dt, c.dt, s->stream));
+        if (fin_kick) { kicked = true; opened = open; }
     } else if (multi) {
         if (int rc = comm_allreduce_sum(s, s->acc, (size_t)cnt, s->is_f64)) return rc;
     }
@@ -954,7 +979,8 @@ int nb_destroy(nb_sim *s)
                     (void *)s->scratch, (void *)s->scalars, (void *)s->fbins, (void *)s->sym.work,
                     (void *)s->sym.row_slot0, (void *)s->sym.row_nslots, (void *)s->sym.col_upto,
                     (void *)s->sym.packed, (void *)s->sym.packed_alt, (void *)s->sym.rowslab, (void *)s->sym.colslab,
-                    (void *)s->prune_cand, (void *)s->prune_rho, (void *)s->prune_state, s->metrics_scratch, s->gen_scalars, s->pos_alt, (void *)s->small_part})
+                    (void *)s->prune_cand, (void *)s->prune_rho, (void *)s->prune_state, s->metrics_scratch, s->gen_scalars, s->pos_alt, (void *)s->small_part,
+                    (void *)s->sums64})
         if (p) (void)hipFree(p);
     if (s->prof_init)
         for (int i = 0; i < PROF_RING; ++i) { (void)hipEventDestroy(s->ev_start[i]); (void)hipEventDestroy(s->ev_stop[i]); }

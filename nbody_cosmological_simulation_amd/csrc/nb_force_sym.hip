@@ -590,7 +590,7 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
                   const int *__restrict__ row_slot0, const int *__restrict__ row_nslots,
                   const int *__restrict__ col_upto, int tile_b, int n, int np,
                   double scale, T *__restrict__ acc, T *__restrict__ vel, T half_dt, int do_kick,
-                  T *__restrict__ pos, T *__restrict__ packed, T dt, int blk0)
+                  T *__restrict__ pos, T *__restrict__ packed, T dt, int blk0, double *__restrict__ sums64)
 {
     __shared__ double s_part[NB_RED_WAVES][D][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -626,6 +626,10 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
 #pragma unroll
             for (int w = 1; w < NB_RED_WAVES; ++w) t += s_part[w][k][lane];
             const size_t idx = (size_t)p * D + k;
+            if (sums64) {                          // multi-GPU, fp32 state: the ranks exchange the unrounded fp64 sums
+                sums64[idx] = t;
+                continue;
+            }
             const T a = (T)(t * scale);            // scale = mass factor of the uniform kernel, else 1
             acc[idx] = a;
             if (do_kick == 1) {
@@ -641,6 +645,27 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
                 packed[(size_t)k * np + p] = x;
             }
         }
+    }
+}
+
+__global__ void __launch_bounds__(NB_BLOCK)
+finish_sums64_kernel(const double *__restrict__ sums64, double scale, float *__restrict__ acc, float *__restrict__ vel,
+                     float *__restrict__ pos, float *__restrict__ packed, long long count, int np, int dim, int mode,
+                     float half_dt, float dt)
+{
+    const long long e = (long long)blockIdx.x * NB_BLOCK + threadIdx.x;
+    if (e >= count) return;
+    const float a = (float)(sums64[e] * scale);
+    acc[e] = a;
+    if (mode == 1) {
+        vel[e] = axpy_rn<float>(vel[e], a, half_dt);
+    } else if (mode == 2) {
+        float v = axpy_rn<float>(vel[e], a, half_dt);
+        v = axpy_rn<float>(v, a, half_dt);
+        const float x = axpy_rn<float>(pos[e], v, dt);
+        vel[e] = v;
+        pos[e] = x;
+        if (packed) packed[(size_t)(e % dim) * np + e / dim] = x;
     }
 }
 
@@ -878,10 +903,20 @@ hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int 
     return hipGetLastError();
 }
 
+hipError_t nb_launch_finish_sums64(const double *sums64, double scale, float *acc, float *vel, float *pos, float *packed,
+                                   int n, int np, int dim, int mode, double half_dt, double dt, hipStream_t st)
+{
+    const long long count = (long long)n * dim;
+    hipLaunchKernelGGL(finish_sums64_kernel, dim3((unsigned)((count + NB_BLOCK - 1) / NB_BLOCK)), dim3(NB_BLOCK), 0, st, sums64,
+                       scale, acc, vel, pos, packed, count, np, dim, mode, (float)half_dt, (float)dt);
+    return hipGetLastError();
+}
+
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
                                 const int *row_nslots, const int *col_upto, int tile_b, int n,
                                 int np, int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
-                                int do_kick, void *pos, void *packed, double dt, hipStream_t st, int p_begin, int p_end)
+                                int do_kick, void *pos, void *packed, double dt, hipStream_t st, int p_begin, int p_end,
+                                double *sums64)
 {
     if (p_end < 0 || p_end > n) p_end = n;
     if (p_end <= p_begin) return hipSuccess;
@@ -890,7 +925,7 @@ hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, cons
 #define NB_RED(TT, DD) \
     hipLaunchKernelGGL((reduce_sym_kernel<TT, DD>), dim3(grid), dim3(64 * NB_RED_WAVES), 0, st, rowslab, (const TT *)colslab, \
                        row_slot0, row_nslots, col_upto, tile_b, n, np, scale, (TT *)acc, (TT *)vel, (TT)half_dt, do_kick, \
-                       (TT *)pos, (TT *)packed, (TT)dt, blk0)
+                       (TT *)pos, (TT *)packed, (TT)dt, blk0, sums64)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64) { if (dim == 2) NB_RED(double, 2); else NB_RED(double, 3); }
     else        { if (dim == 2) NB_RED(float, 2); else NB_RED(float, 3); }

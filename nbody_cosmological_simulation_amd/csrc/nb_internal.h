@@ -118,7 +118,12 @@ hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, cons
                                 int np, int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
                                 int do_kick /* 1: closing kick, 2: + next opening kick + drift + repack */,
                                 void *pos, void *packed, double dt, hipStream_t st,
-                                int p_begin = 0, int p_end = -1 /* particles [p_begin, p_end); -1 = n */);
+                                int p_begin = 0, int p_end = -1 /* particles [p_begin, p_end); -1 = n */,
+                                double *sums64 = nullptr /* instead of acc / kicks: the unscaled, unrounded fp64 sums */);
+// fp32 state, multi-GPU: acc = (float)(sums64 * scale) after the ranks' fp64 sums were added, + the kicks of mode
+// (0 none, 1 closing, 2 closing + next opening + drift + repack) -- the tail of reduce_sym_kernel, after the exchange
+hipError_t nb_launch_finish_sums64(const double *sums64, double scale, float *acc, float *vel, float *pos, float *packed,
+                                   int n, int np, int dim, int mode, double half_dt, double dt, hipStream_t st);
 
 // ---- kernel launchers (implemented in the .hip files) --------------------------------------
 // T = storage/accumulation type of the state (float or double); pa_f32 != 0 selects fp32
@@ -218,6 +223,8 @@ int nb_p2p_device();
 // leapfrog work fused behind the sum: mode 1 closing half kick, 2 + the next step's opening kick + drift (+ repack)
 struct NbP2PKick {
     int mode, dim, np;
+    int f64_to_f32;                // the vector holds fp64 sums, the result (and vel / pos / packed) is fp32:
+    double scale;                  //   result = (float)(sum * scale)
     void *vel, *pos, *packed;      // storage type of the force vector; packed may be null (one-sided kernels)
     double half_dt, dt;
 };

@@ -54,6 +54,8 @@ struct P2PArgs {
     int kick, dim, np;
     void *vel, *pos, *packed;
     double half_dt, dt;
+    int f64_to_f32;             // the units are fp64 sums; dst / vel / pos / packed are fp32: result = (float)(sum * scale)
+    double scale;
 };
 
 struct P2PState {
@@ -165,6 +167,12 @@ __device__ __forceinline__ void p2p_leapfrog(const P2PArgs &a, long long e, T f)
 template <bool F64>
 __device__ __forceinline__ void p2p_finish(const P2PArgs &a, u64 *__restrict__ dst, long long u, u64 s)
 {
+    if (F64 && a.f64_to_f32) {
+        const float f = (float)(__longlong_as_double((long long)s) * a.scale);
+        ((float *)dst)[u] = f;
+        if (a.kick) p2p_leapfrog<float>(a, u, f);
+        return;
+    }
     dst[u] = s;
     if (a.kick) {
         if (F64) {
@@ -321,9 +329,13 @@ size_t nb_p2p_handle_bytes() { return sizeof(hipIpcMemHandle_t); }
 static void p2p_set_kick(P2PArgs &a, const NbP2PKick *k)
 {
     a.kick = 0; a.dim = 1; a.np = 0; a.vel = a.pos = a.packed = nullptr; a.half_dt = a.dt = 0.0;
-    if (k && k->mode) {
-        a.kick = k->mode; a.dim = k->dim; a.np = k->np; a.vel = k->vel; a.pos = k->pos; a.packed = k->packed;
-        a.half_dt = k->half_dt; a.dt = k->dt;
+    a.f64_to_f32 = 0; a.scale = 1.0;
+    if (k) {
+        a.f64_to_f32 = k->f64_to_f32; a.scale = k->scale;
+        if (k->mode) {
+            a.kick = k->mode; a.dim = k->dim; a.np = k->np; a.vel = k->vel; a.pos = k->pos; a.packed = k->packed;
+            a.half_dt = k->half_dt; a.dt = k->dt;
+        }
     }
 }
 

@@ -38,6 +38,8 @@ for name, n, mode in cases:
                  "relerr_v": float(np.abs(v1 - v2).max() / np.abs(v1).max()),
                  "energy": [single.get_total_energy(), multi.get_total_energy()],
                  "kernel": multi.force_kernel_name(),
+                 "same_bits": bool(np.array_equal(single.positions.cpu().numpy(), multi.positions.cpu().numpy()) and
+                                   np.array_equal(single.velocities.cpu().numpy(), multi.velocities.cpu().numpy())),
                  "hash": hashlib.sha256(multi.positions.cpu().numpy().tobytes() + multi.velocities.cpu().numpy().tobytes()).hexdigest()}
     single.close(); multi.close()
 assert N.lib().nb_comm_ready() == world and N.lib().nb_comm_p2p_state() == 2
