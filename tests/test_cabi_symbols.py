@@ -43,6 +43,29 @@ def test_no_gpu_means_loud_failure_not_fallback():
         nb._grid_quantize_safe(torch.rand(4, 4), 16)
 
 
+def test_direct_allreduce_entry_points_fail_loudly_without_a_device():
+    """The setup calls of the direct all-reduce (include/nbody_amd.h, nb_comm_p2p_*) report errors -- they never
+    crash and never pretend -- when there is no GPU, no exported region or no communicator."""
+    import ctypes as C
+    from nbody_cosmological_simulation_amd import _native as N
+    L = N.lib()
+    assert L.nb_comm_p2p_state() == 0 and L.nb_comm_ready() == 0
+    buf = C.create_string_buffer(128)
+    size = C.c_int32(128)
+    if N.device_count() == 0:
+        assert L.nb_comm_p2p_export(0, 0, 1, 1 << 20, buf, C.byref(size)) != 0
+        assert "device" in N.last_error().lower() or "hip" in N.last_error().lower()
+    assert L.nb_comm_p2p_import(buf, 1) != 0                       # nothing exported in this process
+    assert L.nb_comm_p2p_selftest(1, 0.1) != 0
+    x = (C.c_double * 4)()
+    assert L.nb_comm_p2p_allreduce(x, 4, N.NB_F64, 0.1) != 0
+    us = C.c_double(0.0)
+    assert L.nb_comm_allreduce_time(None, 1, 10, C.byref(us)) != 0
+    assert L.nb_comm_allreduce_time(None, 0, 10, C.byref(us)) != 0
+    assert L.nb_comm_p2p_enable(1) == 0 and L.nb_comm_p2p_state() == 0   # enabling without an attached region is a no-op
+    assert L.nb_comm_quiesce() == 0 and L.nb_comm_shutdown() == 0
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "nbody_cosmological_simulation_amd")
     for dirpath, _, files in os.walk(pkg):
