@@ -630,6 +630,50 @@ def g13():
         print("G13", name)
 
 
+def g16():
+    """Config 3's REAL size pinned to the reference itself: distance bins of sampled target rows at N = 65 536.
+    The reference cannot hold the N x N tensor, but its log grid is elementwise once lmin / lmax are known, and those
+    are the logs of the clamped minimum (the diagonal, present in every row) and maximum of r2.  So: r2 rows with the
+    reference's own expression (simulation.py:83-86) on a row subset, the global maximum located by a chunked scan
+    with the same ops, and quantize_distance_squared of the reference applied to a row block that contains a row
+    of the farthest pair -- its bounds are then the global ones, and every element of the block gets the bin the
+    full evaluation would give it."""
+    import hashlib
+    import zlib
+    n = 65536
+    torch.manual_seed(42)
+    pos, vel, mass = ref_galaxy.create_disk_galaxy(n, device="cpu")
+    pos = pos.float()
+    eps2 = 0.1 ** 2                                   # simulation.py:59: Python double
+    best, istar = -1.0, -1
+    for i0 in range(0, n, 512):                       # simulation.py:83-86 on row blocks
+        diff = pos.unsqueeze(0) - pos[i0:i0 + 512].unsqueeze(1)
+        d2 = (diff ** 2).sum(dim=-1) + eps2
+        m = float(d2.max())
+        if m > best:
+            best, istar = m, i0 + int(d2.max(dim=1).values.argmax())
+    rows = sorted({istar, 0, 1, 12345, n // 2, n - 1})
+    diff = pos.unsqueeze(0) - pos[rows].unsqueeze(1)
+    d2 = (diff ** 2).sum(dim=-1) + eps2
+    assert float(d2.max()) == best
+    # the positions themselves travel: torch's CPU transcendentals differ in the last bit between hosts (AVX2 /
+    # AVX-512 code paths), so regenerating the galaxy elsewhere does not reproduce these bits
+    out = dict(rows=np.array(rows, np.int64), istar=istar, r2max=np.float32(best), pos=npy(pos).astype(np.float32),
+               pos_sha256=np.array(hashlib.sha256(npy(pos).tobytes()).hexdigest()))
+    for mode in (PrecisionMode.INT8_SIM, PrecisionMode.INT4_SIM, PrecisionMode.CUSTOM):
+        levels = {PrecisionMode.INT8_SIM: 256, PrecisionMode.INT4_SIM: 16, PrecisionMode.CUSTOM: 64}[mode]
+        q = ref_quant.quantize_distance_squared(d2.clone(), mode)
+        k, lmin, lmax = safe_bins(d2, levels, 0.01, q)
+        k16 = np.ascontiguousarray(k.astype("<i2"))
+        tag = mode.value
+        out[f"{tag}/lmin"], out[f"{tag}/lmax"] = lmin, lmax
+        out[f"{tag}/row_crc"] = np.array([zlib.crc32(k16[r].tobytes()) for r in range(len(rows))], np.uint32)
+        out[f"{tag}/row_hist"] = np.stack([np.bincount(k16[r], minlength=levels) for r in range(len(rows))]).astype(np.int64)
+        out[f"{tag}/row0_head"] = k16[rows.index(0)][:4096]       # the first 4096 bins of target row 0, for a readable failure
+    np.savez_compressed(os.path.join(OUT, "g16_bins_n65536_rows.npz"), **out)
+    print("G16 rows", rows, "r2max", best)
+
+
 def g15():
     """Mixed / unusual dtype combinations through the stock class (quantization.py:58-69 is dtype-polymorphic,
     simulation.py:105 promotes through the mass product)."""
@@ -705,6 +749,6 @@ def g14():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     for w in which:
         globals()[w]()

