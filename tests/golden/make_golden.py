@@ -670,6 +670,23 @@ def g16():
         out[f"{tag}/row_crc"] = np.array([zlib.crc32(k16[r].tobytes()) for r in range(len(rows))], np.uint32)
         out[f"{tag}/row_hist"] = np.stack([np.bincount(k16[r], minlength=levels) for r in range(len(rows))]).astype(np.int64)
         out[f"{tag}/row0_head"] = k16[rows.index(0)][:4096]       # the first 4096 bins of target row 0, for a readable failure
+    # accelerations of the same rows, every stage with the reference's own torch expressions on the row block
+    # (simulation.py:83-112; the hook sees a block with the global bounds, the eye mask is the block's slice of it).
+    # INT8 / INT4 stop before quantize_force (its grid needs the forces of every row).
+    ones = torch.ones(n)
+    eye_rows = torch.zeros(len(rows), n)
+    eye_rows[torch.arange(len(rows)), torch.tensor(rows)] = 1.0
+    for mode in PrecisionMode:
+        diff_m = pos.unsqueeze(0) - pos[rows].unsqueeze(1)
+        dist_sq = (diff_m ** 2).sum(dim=-1) + eps2
+        qd = ref_quant.quantize_distance_squared(dist_sq, mode)
+        cubed = qd ** 1.5
+        ff = 0.001 / cubed
+        ff = ff * ones.unsqueeze(0)
+        ff = ff * (1 - eye_rows)
+        acc = (ff.unsqueeze(-1) * diff_m).sum(dim=1)
+        out[f"{mode.value}/acc_rows"] = npy(acc.double())
+        out[f"{mode.value}/acc_dtype"] = np.array(str(acc.dtype))
     np.savez_compressed(os.path.join(OUT, "g16_bins_n65536_rows.npz"), **out)
     print("G16 rows", rows, "r2max", best)
 

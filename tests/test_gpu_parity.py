@@ -1270,7 +1270,8 @@ def test_config3_full_size_bins_vs_reference_rows(nb):
     """g16: BASELINE config 3 at its real size, distance bins pinned to the REFERENCE itself -- six target rows at
     N = 65 536 (among them a row of the farthest pair, so the row block carries the global lmin / lmax) binned by the
     reference's own quantize_distance_squared (tests/golden/make_golden.py g16).  INT8 / INT4 / CUSTOM: lmin, lmax
-    and every bin of every sampled row bit-identical (row CRCs)."""
+    and every bin of every sampled row bit-identical (row CRCs); all seven modes: the accelerations of those rows
+    against the reference's torch expressions evaluated on the row block."""
     import hashlib
     import zlib
     g = load_golden("g16_bins_n65536_rows.npz")
@@ -1292,6 +1293,21 @@ def test_config3_full_size_bins_vs_reference_rows(nb):
             levels = {"int8_sim": 256, "int4_sim": 16, "custom": 64}[mode]
             assert np.array_equal(np.bincount(k16, minlength=levels), g[f"{mode}/row_hist"][idx]), (mode, r)
             assert zlib.crc32(k16.tobytes()) == int(g[f"{mode}/row_crc"][idx]), (mode, r)
+        sim.close()
+    # accelerations of the same rows against the reference's torch expressions on the row block (simulation.py:83-112);
+    # INT8 / INT4: the golden stops before quantize_force, so the engine's snapped forces sit within half a grid step
+    for mode in MODES:
+        sim = nb.GalaxySimulation(pos, vel, mass, precision_mode=nb.PrecisionMode(mode))
+        acc = sim.accelerations.numpy().astype(np.float64)[rows]
+        ref = g[f"{mode}/acc_rows"]
+        scale = np.abs(ref).max()
+        if mode in ("int8_sim", "int4_sim"):
+            dbg = sim.quant_debug()
+            step = (float(dbg["fmax"]) - float(dbg["fmin"])) / ((256 if mode == "int8_sim" else 16) - 1)
+            assert np.abs(acc - ref).max() <= 0.505 * step + 2e-6 * scale, (mode, np.abs(acc - ref).max(), step)
+        else:
+            tol = 1e-13 if mode == "float64" else 2e-6
+            assert np.abs(acc - ref).max() <= tol * scale, (mode, np.abs(acc - ref).max() / scale)
         sim.close()
 
 

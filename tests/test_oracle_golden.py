@@ -525,3 +525,12 @@ def test_oracle_bins_at_config3_size_vs_reference_rows():
             assert zlib.crc32(k16.tobytes()) == int(g[f"{mode}/row_crc"][ridx]), (mode, r)
             if idx == 0:
                 break          # one all-pairs scan on the CPU is enough here; the GPU test checks every row and mode
+    # accelerations of the sampled rows as the reference's torch expressions give them (simulation.py:83-112 on the row
+    # block); the cast modes need no global scan
+    p_np, m_np = pos.numpy(), mass.numpy()
+    for mode, tol in (("float64", 1e-13), ("float32", 2e-6), ("bfloat16", 2e-6), ("float16", 2e-6)):
+        ref = g[f"{mode}/acc_rows"]
+        scale = np.abs(ref).max()
+        for idx, r in enumerate(rows):
+            got, _ = O.accelerations_rows(p_np, m_np, mode, r, r + 1)
+            assert np.abs(got[0].astype(np.float64) - ref[idx]).max() <= tol * scale, (mode, r)
