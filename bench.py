@@ -268,6 +268,24 @@ def main():
             hashes = [None] * world
             dist.all_gather_object(hashes, checkpoint.state_hash(sim))
         collective["ranks_hold_identical_state"] = len(set(hashes)) == 1
+        # the two carriers against each other on THIS node: five steps from the same initial conditions through the
+        # direct all-reduce and through RCCL (NB_NO_P2P is read when a simulation is created) must agree to
+        # rounding (their summation orders differ) -- a stale or torn read on the direct path would show here
+        if "direct" in collective["carrier"] and collective["rccl_us_per_allreduce"] is not None:
+            def five_steps(rccl_only):
+                if rccl_only:
+                    os.environ["NB_NO_P2P"] = "1"
+                try:
+                    s2 = nb.GalaxySimulation(pos.to(dev), vel.to(dev), mass.to(dev), precision_mode=mode, G=0.001,
+                                             softening=0.1, dt=0.01, device=dev)
+                finally:
+                    os.environ.pop("NB_NO_P2P", None)
+                s2.run(5)
+                x = s2.positions.double().cpu()
+                s2.close()
+                return x
+            xa, xb = five_steps(False), five_steps(True)
+            collective["direct_vs_rccl_relerr_5_steps"] = float((xa - xb).abs().max() / xb.abs().max())
 
     if rank == 0:
         is64 = mode == nb.PrecisionMode.FLOAT64
