@@ -9,7 +9,7 @@ A "step" is one GalaxySimulation.step() (kick-drift-force-kick) over the whole g
 BASELINE.json config 2 -- N=65 536 synthetic disk galaxy, fp32 initial conditions, FLOAT64
 mode, G=1e-3, softening=0.1, dt=0.01.  With N GPUs the SAME galaxy is stepped with the pair
 work partitioned over the ranks (snake-dealt target super-rows of the pair-symmetric kernel)
-and one RCCL all-reduce of the force vectors per step (strong scaling).  The state is resident
+and one all-reduce of the force vectors per step (RCCL or the direct xGMI kernel; strong scaling).  The state is resident
 in HBM before the timed region starts; the K timed steps are ONE native call (nb_step)
 bracketed by barrier + device sync.  `python bench.py --gpus N` without RANK in the
 environment starts the N ranks itself (a child `python -m torch.distributed.run`, before this

@@ -194,7 +194,8 @@ int nb_metrics_tensors(int device, const void *pos, const void *vel, const void 
 /* Partition: every rank holds the full O(N) state.  The pair work is split by
  * TARGET super-rows of the pair-symmetric kernel (snake-dealt, equal pair counts) -- or, on the one-sided
  * kernels, by contiguous SOURCE blocks [rank*N/P, (rank+1)*N/P) -- each rank produces partial accelerations
- * for all particles, and one RCCL all-reduce (sum) of the (n, dim) force vectors per step completes them
+ * for all particles, and one all-reduce (sum) of the (n, dim) force vectors per step -- RCCL, or the direct path
+ * declared below -- completes them
  * (issued in 1..4 prefix slices that overlap the remaining pair work when a step is long enough).
  *
  * ONE communicator per process, shared by every handle of the process:

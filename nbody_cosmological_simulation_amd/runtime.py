@@ -5,7 +5,8 @@ Multi-GPU layout (DESIGN.md "multi-GPU"): every rank holds the full O(N) state a
 partial accelerations of ALL particles over its share of the pair work -- snake-dealt target
 super-rows of the pair-symmetric kernel (the partition at every benchmark size), or a contiguous
 source block [rank*N/P, (rank+1)*N/P) on the one-sided kernels (small N, fp64 state under a cast
-mode) -- and the per-particle force vectors are summed with one RCCL all-reduce per step inside
+mode) -- and the per-particle force vectors are summed with one all-reduce per step (RCCL, or the
+direct xGMI kernel of csrc/nb_p2p.hip for short vectors) inside
 libnbody_amd.  torch.distributed is plumbing only: it carries the 128-byte RCCL unique id from
 rank 0 to the other ranks, once per process: all simulations of a process share ONE communicator
 (nb_comm_init), which only `shutdown()` destroys (collective; never a garbage collector).
@@ -59,7 +60,7 @@ def partition_label(world: int = None) -> str:
     if world <= 1:
         return "single GPU"
     return (f"snake-dealt target super-rows (pair-symmetric) x{world}; one-sided kernels: source j-blocks "
-            f"+ one RCCL all-reduce of the force vectors per step")
+            f"+ one all-reduce of the force vectors per step")
 
 
 def attach_communicator(handle):
