@@ -24,8 +24,17 @@ out = {}
 cases = (("f64", 9000, nb.PrecisionMode.FLOAT64), ("f32", 9000, nb.PrecisionMode.FLOAT32),
          ("f16", 9000, nb.PrecisionMode.FLOAT16), ("int4", 3000, nb.PrecisionMode.INT4_SIM),
          ("int8_big", 9000, nb.PrecisionMode.INT8_SIM), ("f64_onesided", 3000, nb.PrecisionMode.FLOAT64))
+cases += (("f64_n65536", 65536, nb.PrecisionMode.FLOAT64),        # the headline size: production plan of every rank
+          ("f64_d3_unequal", 20481, nb.PrecisionMode.FLOAT64),    # 3-D, four targets per lane, general-mass kernel
+          ("f32_unequal", 20480, nb.PrecisionMode.FLOAT32))
 for name, n, mode in cases:
     pos, vel, mass = galaxy.create_disk_galaxy(n, seed=5, device="cpu")
+    if name == "f64_d3_unequal":
+        g = torch.Generator().manual_seed(7)
+        pos = torch.cat([pos, 0.3 * torch.randn(n, 1, generator=g)], 1)
+        vel = torch.cat([vel, torch.zeros(n, 1)], 1)
+    if "unequal" in name:
+        mass = 0.5 + torch.rand(n, generator=torch.Generator().manual_seed(8))
     runtime.reset_distributed()
     single = nb.GalaxySimulation(pos, vel, mass, precision_mode=mode, device=dev)
     single.run(3); single.run(2)
