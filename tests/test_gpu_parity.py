@@ -1716,8 +1716,8 @@ def test_direct_allreduce_between_processes(nb, world):
     assert res.returncode == 0 and f"P2P-OK {world}" in res.stdout, res.stdout[-2000:] + res.stderr[-6000:]
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_multi_rank_product_path_on_one_gpu(nb, world, tmp_path):
+@pytest.mark.parametrize("world,variant", [(2, ""), (4, ""), (2, "deferred-kick"), (3, "rccl-shaped")])
+def test_multi_rank_product_path_on_one_gpu(nb, world, variant, tmp_path):
     """The REAL multi-rank step on a one-GPU box: `world` processes share the GPU, each is one rank of the engine
     (nb_create with nranks = world: its own snake-dealt work plan, deferred kicks, force quantisation after the sum,
     potential-energy sum) and the direct all-reduce carries every sum (NB_COMM=direct -- RCCL refuses several ranks
@@ -1729,10 +1729,15 @@ def test_multi_rank_product_path_on_one_gpu(nb, world, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outp = str(tmp_path / "multirank.json")
     env = dict(os.environ, NB_ROOT=root, NB_OUT=outp, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NBODY_FORCE_COMM", "NB_NO_P2P", "NB_P2P", "NB_COMM"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NBODY_FORCE_COMM", "NB_NO_P2P", "NB_P2P", "NB_COMM", "NB_P2P_NO_KICK"):
         env.pop(k, None)
+    if variant == "deferred-kick":
+        env["NB_P2P_NO_KICK"] = "1"     # the sum without fused leapfrog work: closing kicks deferred into the next pack launch
+    if variant == "rccl-shaped":
+        env["NB_NO_P2P"] = "1"          # the step as it runs on RCCL (reduce -> in-place all-reduce of acc -> pack), with the
+                                        # direct-only communicator's copy + all-reduce standing in for ncclAllReduce
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-                          "--master-addr", "127.0.0.1", "--master-port", str(29761 + world),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29761 + world + (10 if variant else 0)),
                           os.path.join(root, "tests", "tools", "multirank_worker.py")], env=env, capture_output=True,
                          text=True, timeout=600)
     assert res.returncode == 0 and f"MULTIRANK-OK {world}" in res.stdout, res.stdout[-2000:] + res.stderr[-6000:]
