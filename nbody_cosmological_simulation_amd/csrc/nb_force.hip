@@ -627,8 +627,13 @@ __device__ __forceinline__ float grid_bin_near(float t, double c_log, double c_i
 // caller passes the finished maximum).  Otherwise the body of grid_tables_kernel (one workgroup per NB_LUT_MIN levels).
 template <bool FUSED>
 __device__ __forceinline__ void grid_tables_body(GridTables *__restrict__ tab, int levels, float G, float eps2, float min_val,
-                                                 PruneState *__restrict__ ps, int allow_fast, unsigned int r2max_bits)
+                                                 PruneState *__restrict__ ps, int allow_fast, unsigned int r2max_bits,
+                                                 const double *__restrict__ bounds = nullptr)
 {
+    if (bounds) {                  // tensor-level hook: minimum / maximum of the tensor, found on the device
+        eps2 = (float)bounds[0];
+        r2max_bits = __float_as_uint((float)bounds[1]);
+    }
     __shared__ int s_last;
     __shared__ float s_thr[NB_LUT_MIN], s_lut[NB_LUT_MIN], s_red[NB_LUT_MIN], s_par[4];
     const int k = (FUSED ? 0 : blockIdx.x) * NB_LUT_MIN + threadIdx.x;
@@ -828,6 +833,67 @@ grid_tables_kernel(GridTables *__restrict__ tab, int levels, float G, float eps2
     grid_tables_body<false>(tab, levels, G, eps2, min_val, ps, allow_fast, tab->r2max_bits);
 }
 
+// ---- tensor-level _grid_quantize_safe (quantization.py:91-127) through the same tables ----------------------------
+// The hook used to evaluate a library log twice and an exp once PER ELEMENT in fp64 (fp32 tensors: correctly rounded
+// logf / expf) -- ~600 fp64 instructions per element, 200 us for a 4096 x 4096 tensor.  The bin of an element is a step
+// function of its value, so: plain min / max of the tensor (log is monotone: lmin / lmax are the logs of the clamped
+// extremes), the threshold / value tables for exactly these bounds (the kernel above, bounds read on the device),
+// and one pass that looks every element's bin up (v_log_f32 estimate + two threshold compares, or the binary search
+// for narrow grids) and writes the bin's value.  Non-finite bounds and a degenerate range keep the elementwise formula.
+__global__ void __launch_bounds__(NB_LUT_MIN)
+grid_tables_bounds_kernel(GridTables *__restrict__ tab, int levels, float min_val, const double *__restrict__ bounds)
+{
+    grid_tables_body<false>(tab, levels, 1.0f, 0.0f, min_val, nullptr, 0, 0u, bounds);
+}
+
+__global__ void __launch_bounds__(256)
+grid_quantize_safe_tab_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t count, int levels, float min_val,
+                              const double *__restrict__ bounds, const GridTables *__restrict__ tab, int lp)
+{
+    extern __shared__ float s_tab[];
+    float *s_thr = s_tab, *s_q = s_tab + lp + 1;
+    const float mn = (float)bounds[0], mx = (float)bounds[1];
+    const bool finite = fabsf(mn) < 1e30f && fabsf(mx) < 1e30f;          // false for NaN / inf as well
+    if (!finite) {
+        // the formula element by element, as torch evaluates it (NaN / inf propagate through lmin / lmax)
+        const float tmin = (mn < min_val) ? min_val : mn, tmax = (mx < min_val) ? min_val : mx;
+        const float lmin = (float)log((double)tmin), lmax = (float)log((double)tmax);
+        const float range = __fsub_rn(lmax, lmin), lm1 = (float)(levels - 1);
+        const bool passthrough = range < 1e-10f;
+        for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (int64_t)gridDim.x * 256) {
+            float v = in[idx];
+            v = (v < min_val) ? min_val : v;
+            if (!passthrough) {
+                const float lt = (float)log((double)v);
+                float x = __fmul_rn(__fdiv_rn(__fsub_rn(lt, lmin), range), lm1);
+                const float k = rintf(x);
+                x = __fadd_rn(__fmul_rn(__fdiv_rn(k, lm1), range), lmin);
+                v = (float)exp((double)x);
+                v = (v < min_val) ? min_val : v;
+            }
+            out[idx] = v;
+        }
+        return;
+    }
+    for (int k = threadIdx.x; k <= lp; k += 256) s_thr[k] = k <= levels ? tab->thr[k] : __builtin_inff();
+    for (int k = threadIdx.x; k < levels; k += 256) s_q[k] = tab->qval[k];
+    __syncthreads();
+    if (threadIdx.x == 0) s_thr[levels] = __builtin_inff();      // the table's NaN sentinel would stop the binary search
+    __syncthreads();
+    const bool passthrough = tab->degenerate != 0;
+    const bool use_est = tab->use_est != 0;
+    const float est_a = tab->est_a, est_b = tab->est_b;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (int64_t)gridDim.x * 256) {
+        float v = in[idx];
+        v = (v < min_val) ? min_val : v;
+        if (!passthrough) {
+            const int k = use_est ? grid_bin_estimate(s_thr, v, est_a, est_b, levels - 1) : grid_bin_lookup(s_thr, v, lp);
+            v = s_q[k];
+        }
+        out[idx] = v;
+    }
+}
+
 // Small systems (one launch instead of two per grid evaluation): every workgroup adds its part of the all-pairs
 // maximum; the LAST one to arrive (device-scope counter) reads the finished maximum and builds the tables.
 constexpr int NB_R2MAX_SPLIT = 8;
@@ -1017,6 +1083,23 @@ hipError_t nb_launch_r2max_pruned(const float *pos, int n, int dim, float eps2, 
         hipLaunchKernelGGL((prune_scan_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, cand, eps2, ps, tab);
         return hipGetLastError();
     });
+}
+
+hipError_t nb_launch_grid_quantize_safe_tab(const float *in, float *out, int64_t count, int levels, float min_val,
+                                            const double *bounds, GridTables *tab, hipStream_t st)
+{
+    if (levels < 2 || levels > NB_MAX_LUT) return hipErrorInvalidValue;
+    // the scalar tail of the tables (arrival counter, flags) starts from zero; the arrays are fully rewritten
+    hipError_t e = hipMemsetAsync(&tab->lmin, 0, sizeof(GridTables) - offsetof(GridTables, lmin), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(grid_tables_bounds_kernel, dim3((levels + NB_LUT_MIN - 1) / NB_LUT_MIN), dim3(NB_LUT_MIN), 0, st, tab,
+                       levels, min_val, bounds);
+    const int lp = nb_lut_pad(levels);
+    int grid = (int)((count + 1023) / 1024);
+    grid = grid < 1 ? 1 : (grid > 4096 ? 4096 : grid);
+    hipLaunchKernelGGL(grid_quantize_safe_tab_kernel, dim3(grid), dim3(256), (size_t)(lp + 1 + levels) * sizeof(float), st, in,
+                       out, count, levels, min_val, bounds, tab, lp);
+    return hipGetLastError();
 }
 
 hipError_t nb_launch_grid_tables(GridTables *tab, int levels, float G, float eps2, float min_val, PruneState *ps,

@@ -137,6 +137,10 @@ hipError_t nb_launch_force_f64(const double *pos, const double *mass, double *pa
 hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *partial, const ForceGeom &g,
                                int dim, int hook, int pa, float G, float eps2, const GridTables *tab, int levels,
                                hipStream_t st);
+// tensor-level _grid_quantize_safe of an fp32 tensor through threshold / value tables built for its own bounds
+// (bounds: device, {min, max} of the tensor as doubles; tab: device scratch); levels <= NB_MAX_LUT
+hipError_t nb_launch_grid_quantize_safe_tab(const float *in, float *out, int64_t count, int levels, float min_val,
+                                            const double *bounds, GridTables *tab, hipStream_t st);
 // small systems: all-pairs maximum and the tables of the evaluation in ONE launch (levels <= NB_LUT_MIN)
 hipError_t nb_launch_r2max_tables(const float *pos, const ForceGeom &g, int dim, float eps2, GridTables *tab, int levels,
                                   float G, float min_val, int allow_fast, hipStream_t st);
@@ -178,7 +182,7 @@ hipError_t nb_launch_potential(const void *pos, const void *mass, const ForceGeo
 // tensor-level hooks (quantization.py module functions)
 hipError_t nb_launch_cast_hook(const void *in, int in_dt, void *out, int mode, int64_t count, hipStream_t st);
 // two-stage min/max; partials: device scratch of 2 * NB_MINMAX_BLOCKS doubles
-constexpr int NB_MINMAX_BLOCKS = 256;
+constexpr int NB_MINMAX_BLOCKS = 2048;   // enough waves for HBM speed on N x N tensors (256 ran at 0.6 TB/s)
 hipError_t nb_launch_minmax_generic(const void *in, int is_f64, int64_t count, int log_clamped, double min_val,
                                     double *mn_mx /* device, 2 doubles */, double *partials, hipStream_t st);
 hipError_t nb_launch_grid_quantize(const void *in, void *out, int is_f64, int64_t count, int levels,

@@ -115,13 +115,21 @@ template <> __device__ __forceinline__ double shfl_xor_t<double>(double v, int o
 
 // min/max over `count` elements in two short stages (a single block needs ~40 us for 131 072
 // forces): stage 1 = up to MM_BLOCKS blocks write per-block partials, stage 2 = one block folds them.
-constexpr int MM_BLOCKS = 256;
+constexpr int MM_BLOCKS = NB_MINMAX_BLOCKS;
 
 template <typename T, bool LOGC>
 __device__ __forceinline__ void minmax_block(const T *__restrict__ in, int64_t begin, int64_t end, int64_t stride,
                                              T min_val, T &mn, T &mx)
 {
-    for (int64_t i = begin; i < end; i += stride) {
+    // four independent loads in flight per thread
+    int64_t i = begin;
+    if (!LOGC)
+        for (; i + 3 * stride < end; i += 4 * stride) {
+            const T v0 = in[i], v1 = in[i + stride], v2 = in[i + 2 * stride], v3 = in[i + 3 * stride];
+            mn = nan_min(nan_min(mn, v0), nan_min(v1, nan_min(v2, v3)));
+            mx = nan_max(nan_max(mx, v0), nan_max(v1, nan_max(v2, v3)));
+        }
+    for (; i < end; i += stride) {
         T v = in[i];
         if (LOGC) {
             v = (v < min_val) ? min_val : v;

@@ -374,6 +374,50 @@ def test_tensor_hooks_vs_reference(nb):
                           g["qd2_64/float16"])
 
 
+def test_large_tensor_hook_through_tables_vs_oracle(nb):
+    """Tensors of 2 M elements and more take _grid_quantize_safe through threshold / value tables built for the
+    tensor's own bounds (plain min / max, one lookup pass) instead of a library log + exp per element: the OUTPUT must
+    be bit-identical to the elementwise formula (the oracle's), for every level count the tables serve, with values
+    below the clamp, and NaN / inf / constant tensors must behave as torch's formula does."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    n = 1 << 21
+    base = np.exp(rng.uniform(np.log(1e-3), np.log(5e4), n)).astype(np.float32)       # seven decades, some below 0.01
+    dev = torch.device("cuda:0")
+    for L in (2, 16, 64, 256, 1000, 4096):
+        got = nb._grid_quantize_safe(T(base).to(dev), L).cpu().numpy()
+        ref = O.grid_quantize_safe(base, L)
+        assert np.array_equal(got, ref), (L, int((got != ref).sum()))
+    got = nb.quantize_distance_squared(T(base).to(dev), nb.PrecisionMode.INT8_SIM).cpu().numpy()
+    assert np.array_equal(got, O.grid_quantize_safe(base, 256))
+    got = nb._grid_quantize_safe(T(base).to(dev), 64, min_val=2.0).cpu().numpy()
+    assert np.array_equal(got, O.grid_quantize_safe(base, 64, min_val=2.0))
+    narrow = (1.0 + 1e-4 * rng.random(n)).astype(np.float32)                          # narrow grid: no estimate, binary search
+    assert np.array_equal(nb._grid_quantize_safe(T(narrow).to(dev), 256).cpu().numpy(), O.grid_quantize_safe(narrow, 256))
+    const = np.full(n, 3.0, np.float32)
+    assert np.array_equal(nb._grid_quantize_safe(T(const).to(dev), 16).cpu().numpy(), const)
+    low = np.full(n, 1e-4, np.float32)                                                # everything below the clamp
+    assert np.array_equal(nb._grid_quantize_safe(T(low).to(dev), 16).cpu().numpy(), np.full(n, 0.01, np.float32))
+    for bad in (np.nan, np.inf):
+        t = base.copy()
+        t[12345] = bad
+        got = nb._grid_quantize_safe(T(t).to(dev), 64).cpu().numpy()
+        with np.errstate(all="ignore"):
+            ref = torch_formula_safe(t, 64)
+        assert np.array_equal(got, ref, equal_nan=True), bad
+
+
+def torch_formula_safe(t, levels, min_val=0.01):
+    """quantization.py:91-127 with torch's own CPU ops (the non-finite cases, where only torch defines the answer)."""
+    x = torch.from_numpy(t).clamp(min=min_val)
+    lt = torch.log(x)
+    lmin, lmax = lt.min(), lt.max()
+    if (lmax - lmin) < 1e-10:
+        return x.numpy()
+    k = torch.round((lt - lmin) / (lmax - lmin) * (levels - 1))
+    return torch.exp(k / (levels - 1) * (lmax - lmin) + lmin).clamp(min=min_val).numpy()
+
+
 def test_cuda_tensors_zero_copy_path(nb):
     """State handed over and read back as device tensors (torch is only the allocator here)."""
     g = load_golden("g1_n257_d2_e0.05.npz")
