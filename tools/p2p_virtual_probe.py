@@ -7,7 +7,7 @@ tag = os.path.basename(os.environ.get("NBODY_LIB", "default")) + (" +sync" if os
 tot = 0
 for P in (1, 2, 4, 8):
     for count in (4099, 131072, 262144, 524288):
-        N.check(L.nb_comm_p2p_virtual_test(0, P, count, N.NB_F64, 2, 30, 0.5, C.byref(bad), C.byref(us)))
+        N.check(L.nb_comm_p2p_virtual_test(0, P, count, N.NB_F64, 2, int(os.environ.get("ITERS", "30")), 0.5, C.byref(bad), C.byref(us)))
         tot += bad.value
         print(tag, "P", P, "count", count, "bad", bad.value, "us", round(us.value, 1), flush=True)
 print(tag, "TOTAL", tot, flush=True)
