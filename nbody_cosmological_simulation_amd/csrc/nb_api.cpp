@@ -600,10 +600,15 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready = false, bool *defer_k
                 HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, 0, 0, 0.0, 0.0,
                                       gfac, 0, s->stream));
             if (int rc = prof_begin(s, &slot, false)) return rc;
-            // grid modes: the uniform kernel applies the common mass itself (reduce scale stays 1)
+            // grid modes: the uniform kernel applies the common mass itself (reduce scale stays 1).  On the R = 2 tiling
+            // (N < 20 480: a few hundred short work items, one wave per SIMD) a step is bound by the LATENCY of a sweep,
+            // and the general-mass kernel's four independent scalar pairs per rotation step hide the log / exp chains
+            // better than the packed uniform kernel does (measured INT8 / INT4 us per step, uniform vs general:
+            // N = 6000 61.7 / 55.1 vs 48.3 / 47.6, N = 12 000 100 vs 88; N = 20 000 equal; N = 65 536 0.83 vs 1.24 ms)
+            const bool grid_uniform = s->mass_uniform && sp.r != 2;
             HIPCHK(nb_launch_force_sym_f32((const float *)sp.packed, sp.work, sp.nwork, sp.rowslab,
                                            (float *)sp.colslab, sp.np, c.dim, sp.r,
-                                           hook == HOOK_GRID ? s->mass_uniform : sym_uniform, hook, eps2, s->tab,
+                                           hook == HOOK_GRID ? grid_uniform : sym_uniform, hook, eps2, s->tab,
                                            (float)c.G, (float)s->mass_value, hook == HOOK_GRID ? mode_levels(c) : 0,
                                            s->stream, prof_events(s, slot)));
             s->last_kernel = "force_sym_kernel<float";
