@@ -861,7 +861,11 @@ bool small_ok(const nb_sim *s)
 {
     const nb_config &c = s->cfg;
     const int sdt = s->is_f64 ? NB_F64 : NB_F32;
-    const int nmax = s->knobs.small_max > 0 ? s->knobs.small_max : NB_SMALL_MAX_DEFAULT;
+    // fp32 storage: above 3072 the one-launch kernel runs with 32 lanes per target and the tiled path is ahead
+    // (measured us per step, one launch vs tiled: FLOAT32 N = 3200 13.7 / 10.7, 3584 14.9 / 10.9, 4096 15.9 / 13.4;
+    // CUSTOM 3584 32.8 / 30.9; INT4 4096 39.5 / 40.1 -- equal; up to 3072 one launch wins or ties everywhere);
+    // fp64 keeps it to 4096 (17.2 against 18.9)
+    const int nmax = s->knobs.small_max > 0 ? s->knobs.small_max : (s->is_f64 ? NB_SMALL_MAX_DEFAULT : 3072);
     if (s->knobs.no_smalln || c.n > nmax || comm_active(s) || c.nranks != 1 || !s->have_acc) return false;
     if (grid_mode(c.mode) && (s->is_f64 || mode_levels(c) > NB_LUT_MIN || mode_levels(c) < 2)) return false;
     if (s->is_f64 != (c.mode == NB_FLOAT64)) return false;           // fp64 state under a cast mode: tuned one-sided kernel

@@ -1826,7 +1826,9 @@ def test_small_system_single_launch_step_vs_oracle(nb, monkeypatch, n, d, unequa
         s.run(2)
         return s
     sim = run()
-    assert sim.force_kernel_name() == "small_step_kernel"
+    # one launch per step up to N = 3072 with fp32 state, 4096 with fp64 state (above, the tiled path is ahead)
+    expect_small = n <= 3072 or mode == "float64"
+    assert (sim.force_kernel_name() == "small_step_kernel") == expect_small
     ref = O.OracleSim(pos, vel, mass, mode)
     ref.run(5)
     monkeypatch.setenv("NB_NO_SMALLN", "1")
