@@ -1,11 +1,11 @@
 """Tensor-level hooks (quantization.py:21-157 through the C-ABI) on N x N tensors resident on the GPU: time per call and
 the HBM traffic it implies (read + write of the tensor = 8 bytes per element, the grid modes read it twice)."""
 import os, sys, time, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nbody_cosmological_simulation_amd as nb
 from nbody_cosmological_simulation_amd import quantization as Q
 
-for n in (1024, 4096, 8192):
+for n in ([int(a) for a in sys.argv[1:]] or [1024, 4096, 8192]):
     t = (torch.rand(n, n, device="cuda") * 100 + 0.01).float()
     for name, fn in (("quantize_distance_squared INT8", lambda: Q.quantize_distance_squared(t, nb.PrecisionMode.INT8_SIM)),
                      ("quantize_distance_squared FLOAT16", lambda: Q.quantize_distance_squared(t, nb.PrecisionMode.FLOAT16)),
