@@ -811,7 +811,9 @@ __device__ __forceinline__ void grid_tables_body(GridTables *__restrict__ tab, i
         const float lmag = fmaxf(fabsf(__builtin_amdgcn_logf(tmin)), fabsf(__builtin_amdgcn_logf(tmax)));
         const float ulp_log = __uint_as_float((__float_as_uint(fmaxf(lmag, 1.0f)) & 0x7f800000u)) * 1.1920929e-7f;
         const float ulp_ne = __uint_as_float((__float_as_uint((float)levels) & 0x7f800000u)) * 1.1920929e-7f;
-        const float eta = 4.0f * est_a * ulp_log + ulp_ne;
+        // ... and the pair loop's estimate takes r2 from fused multiply-adds: within 4 ulp (4.8e-7 relative, 6.9e-7 in
+        // log2) of the reference's separately rounded r2
+        const float eta = 4.0f * est_a * ulp_log + ulp_ne + 8.0e-7f * est_a;
         const float delta = 2.0f * (maxdev + eta);
         tab->fast_ok = (fast_try && delta < 0.05f && maxrel <= 2.0e-6f) ? 1 : 0;
         tab->sure_lim = 0.5f - delta;

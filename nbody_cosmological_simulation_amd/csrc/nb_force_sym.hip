@@ -21,6 +21,11 @@
 //   than one per row).  Row sums go to per-(row, chunk) slots.  reduce_sym_kernel adds slots and
 //   slabs in a fixed order: no atomics, run-to-run bit-identical.
 #include "nb_device.h"
+#ifdef NB_GRID_R2_EXACT
+#define NB_GRID_R2_EXACT_V 1
+#else
+#define NB_GRID_R2_EXACT_V 0
+#endif
 
 #include <hip/hip_ext.h>
 
@@ -146,9 +151,23 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
                     // reference op order, one rounding per op, no FMA (bit-identical r2)
 #pragma unroll
                     for (int k = 0; k < D; ++k) d[k] = __fsub_rn(xj[rj][k], xi[ri][k]);
-                    float r2 = __fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1]));
-                    if (D == 3) r2 = __fadd_rn(r2, __fmul_rn(d[2], d[2]));
-                    r2 = __fadd_rn(r2, eps2);
+                    float r2;
+#ifndef NB_GRID_R2_EXACT
+                    if (HOOK == HOOK_GRID && (EST == GRID_FAST || EST == GRID_FAST_CLAMP)) {
+                        // the ESTIMATE may take r2 from fused multiply-adds (D ops instead of 2 D; within 4 ulp of the
+                        // reference's r2 = 7e-7 * est_a bins, which sure_lim allows for): a pair far from every bin edge
+                        // has the same bin either way, and the rare wave with a pair near an edge recomputes the
+                        // reference's r2 bit for bit before it consults the thresholds
+                        r2 = __builtin_fmaf(d[D - 1], d[D - 1], eps2);
+#pragma unroll
+                        for (int k = D - 2; k >= 0; --k) r2 = __builtin_fmaf(d[k], d[k], r2);
+                    } else
+#endif
+                    {
+                        r2 = __fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1]));
+                        if (D == 3) r2 = __fadd_rn(r2, __fmul_rn(d[2], d[2]));
+                        r2 = __fadd_rn(r2, eps2);
+                    }
                     if (HOOK == HOOK_GRID) {
                         if (EST == GRID_DEGENERATE) {
                             w = inv_r3_sym((r2 < 0.01f) ? 0.01f : r2, c15, c1875) * ga.gfac;
@@ -158,7 +177,10 @@ __device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (
                             float kf = __builtin_rintf(ne);
                             const float dev = __builtin_fabsf(ne - kf);
                             if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(dev <= ga.sure_lim)) != 0ull, 0)) {
-                                w = ga.lut[grid_bin_floor_estimate(ga.thr, r2, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
+                                float r2e = __fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1]));
+                                if (D == 3) r2e = __fadd_rn(r2e, __fmul_rn(d[2], d[2]));
+                                r2e = __fadd_rn(r2e, eps2);
+                                w = ga.lut[grid_bin_floor_estimate(ga.thr, r2e, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
                             } else {
                                 if (EST == GRID_FAST_CLAMP) kf = __builtin_amdgcn_fmed3f(kf, -ga.kcf, 1e30f);
                                 w = __builtin_amdgcn_exp2f(__builtin_fmaf(kf, ga.c1, ga.c0c));
@@ -237,7 +259,9 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                 for (int k = 0; k < D; ++k) d[k] = xj2[h][k] - xi[ri][k];
                 f2 r2;
 #ifndef NB_F32_R2_EXACT
-                if constexpr (HOOK == HOOK_NONE) {
+                if constexpr (HOOK == HOOK_NONE || (HOOK == HOOK_GRID && (EST == GRID_FAST || EST == GRID_FAST_CLAMP) && !NB_GRID_R2_EXACT_V)) {
+                    // grid modes, table-free path: only the ESTIMATE uses this r2 (see the scalar sweep above); the
+                    // fallback below recomputes the reference's r2.
                     // FLOAT32 mode has no rounding DECISION hanging on r2 (no bins, no half-type cast), so r2 is built with
                     // fused multiply-adds: D packed ops instead of 2 D, and closer to the exact r2 than the reference's
                     // separately rounded sum (summed forces vs exact: rms 1.12e-8 against 1.21e-8 with the unfused form and
@@ -250,7 +274,7 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
 #endif
                 {
                     r2 = d[0] * d[0] + d[1] * d[1];         // one rounding per op (contraction is off): the reference's r2, bit for bit
-                    if (D == 3) r2 = r2 + d[2] * d[2];
+                    if constexpr (D == 3) r2 = r2 + d[2] * d[2];
                     r2 = r2 + eps2;
                 }
                 f2 w;
@@ -267,8 +291,11 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                         const f2 fr = ne - kf;
                         const float dev = __builtin_fmaxf(__builtin_fabsf(fr.x), __builtin_fabsf(fr.y));
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(dev <= ga.sure_lim)) != 0ull, 0)) {   // also taken for NaN
-                            w.x = ga.lut[grid_bin_floor_estimate(ga.thr, r2.x, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
-                            w.y = ga.lut[grid_bin_floor_estimate(ga.thr, r2.y, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
+                            f2 r2e = d[0] * d[0] + d[1] * d[1];     // the reference's r2, bit for bit (one rounding per op)
+                            if constexpr (D == 3) r2e = r2e + d[2] * d[2];
+                            r2e = r2e + eps2;
+                            w.x = ga.lut[grid_bin_floor_estimate(ga.thr, r2e.x, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
+                            w.y = ga.lut[grid_bin_floor_estimate(ga.thr, r2e.y, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
                         } else {
                             if (EST == GRID_FAST_CLAMP)
                                 kf = f2{__builtin_amdgcn_fmed3f(kf.x, -ga.kcf, 1e30f), __builtin_amdgcn_fmed3f(kf.y, -ga.kcf, 1e30f)};

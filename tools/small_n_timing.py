@@ -9,6 +9,8 @@ for n in ns:
     if __import__("os").environ.get("DIM") == "3":          # 3-D cloud (reality_glitch_tests.py runs (N,3) tensors)
         torch.manual_seed(0)
         pos, vel = torch.randn(n, 3) * 5, torch.randn(n, 3) * 0.05
+    if __import__("os").environ.get("MASS") == "unequal":    # jitter_test.py:76 runs unequal masses
+        mass = 0.5 + torch.rand(n, generator=torch.Generator().manual_seed(1))
     sim = nb.GalaxySimulation(pos.cuda(), vel.cuda(), mass.cuda(), precision_mode=mode)
     t = time.perf_counter()
     while time.perf_counter() - t < 0.1:          # ~100 ms of steps: past the clock ramp
