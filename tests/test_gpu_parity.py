@@ -994,6 +994,78 @@ def test_symmetric_grid_kernel_pair_selection(nb, monkeypatch, mode, masses):
     assert torch.isnan(sim.accelerations).all()
 
 
+@pytest.mark.parametrize("r", [2, 4])
+@pytest.mark.parametrize("levels", [256, 16, 64, 1000])
+def test_grid_force_kernel_decides_pairs_at_the_bin_edges(nb, monkeypatch, levels, r):
+    """Adversarial input for the table-free pair path of the FORCE kernel (its own bin decisions are not what
+    nb_quant_bins_rows reports): a star at the origin and stars on a line whose r2 to it sits one fp32 step below /
+    exactly on / one step above a bin threshold, for every threshold between r2 = 1 and 1.7 -- the zone where the
+    estimate (v_log_f32, r2 from fused multiply-adds) must hand over to the exact thresholds with the reference's r2.
+    All these pairs weigh about the same in the origin star's force, so ONE pair in a wrong bin moves it by
+    (bin step) / (number of stars): 1e-4 ... 1e-2, far above the 2e-6 asserted.  The grids of INT8 (256 levels) and INT4
+    (16) are run as CUSTOM grids of the same level counts -- the same kernel and tables without the force
+    quantisation that would blur a wrong bin.  (Negative control, run once by hand: with the safety margin of the
+    estimate removed -- sure_lim = 0.5 -- this test fails with errors of 1e-4.)"""
+    from oracle import oracle as O
+    monkeypatch.setenv("NB_SYM", "1")
+    monkeypatch.setenv("NB_SYM_R", str(r))
+    mode = "custom"
+    eps2 = np.float32(0.1 * 0.1)
+    xmax = np.float32(1.3)
+
+    def r2_of(x):                       # the reference's fp32 r2 of the pair (origin, (x, 0)), op by op
+        x = np.asarray(x, np.float32)
+        return (x * x + np.float32(0.0)) + eps2
+
+    r2max = r2_of(xmax)
+
+    def bins(t):                        # bins of candidate r2 values under the system's own bounds (diagonal, farthest pair)
+        arr = np.concatenate([[eps2, r2max], np.asarray(t, np.float32)]).astype(np.float32)
+        _, b, _, _ = O.grid_quantize_safe(arr, levels, bins=True)
+        return b[2:]
+
+    k_lo, k_hi = int(bins([1.0])[0]) + 1, int(bins([1.68])[0])
+    xs = []
+    for k in range(k_lo, k_hi + 1):
+        lo, hi = np.float32(1.0).view(np.uint32).astype(np.int64), np.float32(1.7).view(np.uint32).astype(np.int64)
+        while hi - lo > 1:              # smallest fp32 r2 whose bin is >= k
+            mid = (lo + hi) // 2
+            if bins([np.array(mid, np.uint32).view(np.float32)])[0] >= k:
+                hi = mid
+            else:
+                lo = mid
+        thr = np.array(hi, np.uint32).view(np.float32)
+        # positions whose r2 lands just below / on / just above the threshold
+        x0 = np.float32(np.sqrt(np.float64(thr) - np.float64(eps2)))
+        cand = (x0.view(np.uint32).astype(np.int64) + np.arange(-6, 7)).astype(np.uint32).view(np.float32)
+        rr = r2_of(cand)
+        below, above = cand[rr < thr], cand[rr >= thr]
+        xs += [below.max(), above.min()]
+        if (rr == thr).any():
+            xs.append(cand[rr == thr][0])
+    xs = np.unique(np.array(xs, np.float32))
+    rng = np.random.default_rng(5)
+    n = max(300 if r == 4 else 200, int(xs.size) + 50)
+    fill = rng.uniform(1.0, 1.29, n - 2 - xs.size).astype(np.float32)
+    pos = np.zeros((n, 2), np.float32)
+    pos[1:1 + xs.size, 0] = xs
+    pos[1 + xs.size:n - 1, 0] = fill
+    pos[n - 1, 0] = xmax
+    mass = np.full(n, 0.01, np.float32)
+    ref, dbg = O.accelerations(pos, mass, mode, levels=levels, debug=True)
+    edge_bins = dbg["d2bins"][0, 1:1 + xs.size]
+    assert len(set(edge_bins.tolist())) >= max(1, (k_hi - k_lo) // 2)   # the constructed stars do straddle the thresholds
+    sim = nb.GalaxySimulation(T(pos), torch.zeros(n, 2), T(mass), precision_mode=nb.PrecisionMode(mode),
+                              custom_levels=levels)
+    assert sim.force_kernel_name().startswith("force_sym_kernel<float")
+    got = sim.quant_debug(bins=True)
+    assert np.float32(got["lmax"]) == np.float32(dbg["lmax"])
+    assert np.array_equal(got["d2bins"], dbg["d2bins"])
+    acc = sim.accelerations.numpy().astype(np.float64)
+    assert abs(acc[0, 0] - ref[0, 0]) <= 2e-6 * abs(ref[0, 0]), (acc[0], ref[0])
+    assert np.abs(acc - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_symmetric_plan_of_every_rank_adds_up(nb, monkeypatch, world):
     """Multi-GPU by construction: the pair-symmetric work lists the P ranks would run (snake-dealt super-rows,
