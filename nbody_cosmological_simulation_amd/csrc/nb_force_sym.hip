@@ -617,7 +617,8 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
                   const int *__restrict__ row_slot0, const int *__restrict__ row_nslots,
                   const int *__restrict__ col_upto, int tile_b, int n, int np,
                   double scale, T *__restrict__ acc, T *__restrict__ vel, T half_dt, int do_kick,
-                  T *__restrict__ pos, T *__restrict__ packed, T dt, int blk0, double *__restrict__ sums64)
+                  T *__restrict__ pos, T *__restrict__ packed, T dt, int blk0, double *__restrict__ sums64,
+                  double *__restrict__ mm_part)
 {
     __shared__ double s_part[NB_RED_WAVES][D][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -646,6 +647,9 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
 #pragma unroll
     for (int k = 0; k < D; ++k) s_part[g][k][lane] = s[k];
     __syncthreads();
+    // INT8 / INT4 on one GPU: the min / max of the finished forces for quantize_force, one pair per workgroup
+    // (NaN-propagating like torch.min / max), so the step needs no reduction launch of its own
+    double mm_lo = __builtin_inf(), mm_hi = -__builtin_inf();
     if (g == 0 && p < n) {
 #pragma unroll
         for (int k = 0; k < D; ++k) {
@@ -659,6 +663,11 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
             }
             const T a = (T)(t * scale);            // scale = mass factor of the uniform kernel, else 1
             acc[idx] = a;
+            if (mm_part) {
+                const double ad = (double)a;
+                mm_lo = (ad != ad || mm_lo != mm_lo) ? __builtin_nan("") : (ad < mm_lo ? ad : mm_lo);
+                mm_hi = (ad != ad || mm_hi != mm_hi) ? __builtin_nan("") : (ad > mm_hi ? ad : mm_hi);
+            }
             if (do_kick == 1) {
                 vel[idx] = axpy_rn<T>(vel[idx], a, half_dt);
             } else if (do_kick == 2) {
@@ -672,6 +681,15 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
                 packed[(size_t)k * np + p] = x;
             }
         }
+    }
+    if (mm_part && g == 0) {               // wave-uniform
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ol = __shfl_xor(mm_lo, off, 64), oh = __shfl_xor(mm_hi, off, 64);
+            mm_lo = (ol != ol || mm_lo != mm_lo) ? __builtin_nan("") : (ol < mm_lo ? ol : mm_lo);
+            mm_hi = (oh != oh || mm_hi != mm_hi) ? __builtin_nan("") : (oh > mm_hi ? oh : mm_hi);
+        }
+        if (lane == 0) { mm_part[2 * blockIdx.x] = mm_lo; mm_part[2 * blockIdx.x + 1] = mm_hi; }
     }
 }
 
@@ -943,7 +961,7 @@ hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, cons
                                 const int *row_nslots, const int *col_upto, int tile_b, int n,
                                 int np, int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
                                 int do_kick, void *pos, void *packed, double dt, hipStream_t st, int p_begin, int p_end,
-                                double *sums64)
+                                double *sums64, double *mm_part)
 {
     if (p_end < 0 || p_end > n) p_end = n;
     if (p_end <= p_begin) return hipSuccess;
@@ -952,7 +970,7 @@ hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, cons
 #define NB_RED(TT, DD) \
     hipLaunchKernelGGL((reduce_sym_kernel<TT, DD>), dim3(grid), dim3(64 * NB_RED_WAVES), 0, st, rowslab, (const TT *)colslab, \
                        row_slot0, row_nslots, col_upto, tile_b, n, np, scale, (TT *)acc, (TT *)vel, (TT)half_dt, do_kick, \
-                       (TT *)pos, (TT *)packed, (TT)dt, blk0, sums64)
+                       (TT *)pos, (TT *)packed, (TT)dt, blk0, sums64, mm_part)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64) { if (dim == 2) NB_RED(double, 2); else NB_RED(double, 3); }
     else        { if (dim == 2) NB_RED(float, 2); else NB_RED(float, 3); }

@@ -119,7 +119,8 @@ hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, cons
                                 int do_kick /* 1: closing kick, 2: + next opening kick + drift + repack */,
                                 void *pos, void *packed, double dt, hipStream_t st,
                                 int p_begin = 0, int p_end = -1 /* particles [p_begin, p_end); -1 = n */,
-                                double *sums64 = nullptr /* instead of acc / kicks: the unscaled, unrounded fp64 sums */);
+                                double *sums64 = nullptr /* instead of acc / kicks: the unscaled, unrounded fp64 sums */,
+                                double *mm_part = nullptr /* per-workgroup {min, max} of the forces written (whole-range launches) */);
 // fp32 state, multi-GPU: acc = (float)(sums64 * scale) after the ranks' fp64 sums were added, + the kicks of mode
 // (0 none, 1 closing, 2 closing + next opening + drift + repack) -- the tail of reduce_sym_kernel, after the exchange
 hipError_t nb_launch_finish_sums64(const double *sums64, double scale, float *acc, float *vel, float *pos, float *packed,
@@ -261,4 +262,4 @@ hipError_t nb_launch_small_step(const void *pos_in, void *pos_out, void *vel, vo
 // second half of nb_launch_force_quant_step with caller-provided min / max partials (nblocks pairs of doubles)
 hipError_t nb_launch_force_quant_finish(float *acc, int64_t count, int levels, const double *partials, int nblocks,
                                         double *mn_mx, int16_t *bins, float *vel, float *pos, double half_dt, double dt,
-                                        int kick, hipStream_t st);
+                                        int kick, hipStream_t st, float *packed = nullptr, int np = 0, int dim = 1);

@@ -557,12 +557,12 @@ hipError_t nb_launch_force_quant_step(float *acc, int64_t count, int levels, dou
 
 hipError_t nb_launch_force_quant_finish(float *acc, int64_t count, int levels, const double *partials, int nblocks,
                                         double *mn_mx, int16_t *bins, float *vel, float *pos, double half_dt, double dt,
-                                        int kick, hipStream_t st)
+                                        int kick, hipStream_t st, float *packed, int np, int dim)
 {
     int grid = (int)((count + 255) / 256);
     grid = grid > 2048 ? 2048 : grid;
     hipLaunchKernelGGL(force_quant_finish_kernel, dim3(grid), dim3(256), 0, st, acc, count, levels, partials, nblocks, mn_mx,
-                       bins, vel, pos, (float)half_dt, (float)dt, kick, (float *)nullptr, 0, 1);
+                       bins, vel, pos, (float)half_dt, (float)dt, kick, packed, np, dim);
     return hipGetLastError();
 }
 

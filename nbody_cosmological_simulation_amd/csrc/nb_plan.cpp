@@ -37,6 +37,7 @@ NbKnobs nb_read_knobs()
     k.no_p2p_kick = getenv("NB_P2P_NO_KICK") != nullptr;
     k.no_small_fuse = getenv("NB_NO_SMALL_FUSE") != nullptr;
     k.no_x64 = getenv("NB_NO_X64") != nullptr;
+    k.no_red_mm = getenv("NB_NO_RED_MM") != nullptr;
     k.small_max = std::max(0, env_int("NB_SMALL_MAX", 0));
     k.small_lanes = env_int("NB_SMALL_LANES", 0);
     if (k.small_lanes != 16 && k.small_lanes != 32 && k.small_lanes != 64) k.small_lanes = 0;

@@ -30,6 +30,7 @@ struct NbKnobs {
     int small_lanes = 0;
     bool no_grid_fast = false;   // NB_NO_GRID_FAST: grid modes always read their tables (A/B of the table-free pair path)
     bool no_p2p = false;         // NB_NO_P2P: force vectors always go through RCCL (never the direct xGMI all-reduce)
+    bool no_red_mm = false;      // NB_NO_RED_MM: INT8 / INT4 steps keep their own min/max launch (A/B)
     bool no_x64 = false;         // NB_NO_X64: multi-GPU fp32 modes exchange fp32 partial forces (not the fp64 sums)
     bool no_small_fuse = false;  // NB_NO_SMALL_FUSE: small grid steps launch max-r2 and tables separately (A/B)
     bool no_p2p_kick = false;    // NB_P2P_NO_KICK: the direct all-reduce does not fuse the kicks / drift / repack (A/B)
