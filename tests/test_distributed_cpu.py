@@ -180,6 +180,36 @@ def test_symmetric_plans_cover_every_tile_pair_once(monkeypatch, n, is_f64, worl
         assert p0["nchunks"] == 3
 
 
+def _p2p_vote_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nbody_cosmological_simulation_amd import _native as N, runtime
+        runtime.init_distributed(device=0)
+        # no GPU here: the export fails on every rank; the setup must come back False on every rank (unanimous vote,
+        # nobody left waiting in a collective) and leave the library without a direct path
+        ok = runtime.attach_direct_allreduce(0, world, rank)
+        state = N.lib().nb_comm_p2p_state()
+        label = runtime._p2p_log["state"]
+        torch.save({"ok": ok, "state": state, "label": label}, os.path.join(out, f"p2p_{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the behaviour without a GPU")
+def test_direct_allreduce_setup_votes_no_without_a_gpu(tmp_path):
+    """runtime.attach_direct_allreduce between two gloo ranks on a machine without a GPU: every rank's export fails,
+    the all-gathered verdict is a unanimous no, no rank hangs, RCCL stays the carrier."""
+    world, port, out = 2, _free_port(), str(tmp_path)
+    mp.spawn(_p2p_vote_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        got = torch.load(os.path.join(out, f"p2p_{r}.pt"))
+        assert got["ok"] is False and got["state"] == 0
+        assert got["label"].startswith("disabled")
+
+
 def test_plan_choice_is_rank_independent():
     """Every rank must take the same decision between the symmetric plan and the one-sided source blocks."""
     for n in (700, 3000, 4096, 9000, 40000):
