@@ -691,6 +691,66 @@ def g16():
     print("G16 rows", rows, "r2max", best)
 
 
+def g17():
+    """BASELINE config 2's real size, one full leapfrog step and the energies from the reference's own torch
+    expressions evaluated on row blocks (simulation.py:83-112 for the forces, :132-141 for the step, :172-190 for the
+    energies): N = 65 536, FLOAT64 mode, the fp32 initial positions of g16 with zero velocities (fp32-typed first
+    evaluation, fp64 afterwards -- the dtype promotion of the stock class happens by itself in these expressions).
+    Every row's force is needed for the step, so the two evaluations cost ~2 x 128 row blocks; stored: 2048 sampled
+    rows of the state after the step, the energies before and after.  The block sums of the potential energy are
+    added in fp64 (the reference would add the whole N x N tensor at once: same terms, rounding-level difference)."""
+    n = 65536
+    g16_ = np.load(os.path.join(OUT, "g16_bins_n65536_rows.npz"))
+    pos = torch.from_numpy(g16_["pos"]).clone()
+    vel = torch.zeros_like(pos)
+    masses = torch.ones(n)
+    G, dt, eps2 = 0.001, 0.01, 0.1 ** 2
+    mode = PrecisionMode.FLOAT64
+
+    def forces(p):
+        out = []
+        for i0 in range(0, n, 256):
+            rows = torch.arange(i0, min(i0 + 256, n))
+            diff = p.unsqueeze(0) - p[rows].unsqueeze(1)
+            dist_sq = (diff ** 2).sum(dim=-1) + eps2
+            qd = ref_quant.quantize_distance_squared(dist_sq, mode)
+            ff = G / (qd ** 1.5)
+            ff = ff * masses.unsqueeze(0)
+            eye_rows = torch.zeros(len(rows), n)
+            eye_rows[torch.arange(len(rows)), rows] = 1.0
+            ff = ff * (1 - eye_rows)
+            out.append((ff.unsqueeze(-1) * diff).sum(dim=1))
+        return torch.cat(out)
+
+    def potential(p, m):
+        total = 0.0
+        for i0 in range(0, n, 256):
+            rows = torch.arange(i0, min(i0 + 256, n))
+            diff = p.unsqueeze(0) - p[rows].unsqueeze(1)
+            dist = torch.sqrt((diff ** 2).sum(dim=-1) + eps2)
+            mass_prod = m.unsqueeze(0) * m[rows].unsqueeze(1)
+            mask = (torch.arange(n).unsqueeze(0) > rows.unsqueeze(1)).to(dist.dtype)        # triu(diagonal=1), these rows
+            total += float((mass_prod * mask / dist).double().sum())
+        return -G * total
+
+    def kinetic(v, m):
+        return float(0.5 * (m * (v ** 2).sum(dim=-1)).sum())
+
+    acc = forces(pos)                                   # __init__ (simulation.py:69)
+    e0 = (kinetic(vel, masses), potential(pos, masses))
+    vel = vel + acc * (dt / 2)                          # step (simulation.py:132-141)
+    pos1 = pos + vel * dt
+    acc1 = forces(pos1)
+    vel1 = vel + acc1 * (dt / 2)
+    e1 = (kinetic(vel1, masses), potential(pos1, masses))
+    rows = np.sort(np.random.default_rng(17).choice(n, 2048, replace=False))
+    np.savez_compressed(os.path.join(OUT, "g17_step_n65536.npz"), rows=rows, acc0=npy(acc.double())[rows],
+                        pos1=npy(pos1.double())[rows], vel1=npy(vel1.double())[rows], acc1=npy(acc1.double())[rows],
+                        e0=np.array(e0), e1=np.array(e1),
+                        dtypes=np.array([str(acc.dtype), str(pos1.dtype), str(vel1.dtype), str(acc1.dtype)]))
+    print("G17", e0, e1, acc.dtype, pos1.dtype)
+
+
 def g15():
     """Mixed / unusual dtype combinations through the stock class (quantization.py:58-69 is dtype-polymorphic,
     simulation.py:105 promotes through the mass product)."""
@@ -766,6 +826,6 @@ def g14():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for w in which:
         globals()[w]()

@@ -1382,6 +1382,33 @@ def test_g13_bins_at_scale_vs_reference(nb, fname, mode):
         assert np.abs(acc.astype(np.float64) - ref).max() <= 1.01 * step
 
 
+def test_config2_full_size_step_and_energies_vs_reference_ops(nb):
+    """g17: BASELINE config 2 at its real size against the reference's own arithmetic -- N = 65 536, FLOAT64 mode, fp32
+    initial conditions: the first force evaluation, one full leapfrog step (positions, velocities, second force
+    evaluation) on 2048 sampled rows, and the kinetic / potential energies before and after, all from the reference's
+    torch expressions evaluated on row blocks (tests/golden/make_golden.py g17; the reference itself cannot hold the
+    N x N tensors).  north_star asks for 1e-10; 1e-12 is asserted."""
+    g = load_golden("g17_step_n65536.npz")
+    pos = torch.from_numpy(load_golden("g16_bins_n65536_rows.npz")["pos"])
+    n = pos.shape[0]
+    sim = nb.GalaxySimulation(pos, torch.zeros_like(pos), torch.ones(n), precision_mode=nb.PrecisionMode.FLOAT64)
+    rows = g["rows"]
+    assert str(sim.accelerations.dtype) == str(g["dtypes"][0]) and sim.positions.dtype == torch.float32
+    a_scale, x_scale = np.abs(g["acc0"]).max(), np.abs(g["pos1"]).max()
+    assert np.abs(sim.accelerations.numpy()[rows] - g["acc0"]).max() <= 1e-13 * a_scale
+    assert sim.get_kinetic_energy() == g["e0"][0]
+    # before the first step the state is fp32-typed: the reference's own PE is an fp32 sum of fp32 terms there (the
+    # golden adds the same fp32 terms in fp64), so fp32 accuracy is the meaningful bar; after the step everything is fp64
+    assert abs(sim.get_potential_energy() - g["e0"][1]) <= 2e-6 * abs(g["e0"][1])
+    sim.step()
+    assert [str(t.dtype) for t in (sim.positions, sim.velocities, sim.accelerations)] == [str(d) for d in g["dtypes"][1:]]
+    assert np.abs(sim.positions.numpy()[rows] - g["pos1"]).max() <= 1e-13 * x_scale
+    assert np.abs(sim.accelerations.numpy()[rows] - g["acc1"]).max() <= 1e-12 * a_scale
+    assert np.abs(sim.velocities.numpy()[rows] - g["vel1"]).max() <= 1e-12 * np.abs(g["vel1"]).max()
+    assert abs(sim.get_kinetic_energy() - g["e1"][0]) <= 1e-12 * abs(g["e1"][0])
+    assert abs(sim.get_potential_energy() - g["e1"][1]) <= 1e-12 * abs(g["e1"][1])
+
+
 def test_config3_full_size_bins_vs_reference_rows(nb):
     """g16: BASELINE config 3 at its real size, distance bins pinned to the REFERENCE itself -- six target rows at
     N = 65 536 (among them a row of the farthest pair, so the row block carries the global lmin / lmax) binned by the

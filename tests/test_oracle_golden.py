@@ -534,3 +534,24 @@ def test_oracle_bins_at_config3_size_vs_reference_rows():
         for idx, r in enumerate(rows):
             got, _ = O.accelerations_rows(p_np, m_np, mode, r, r + 1)
             assert np.abs(got[0].astype(np.float64) - ref[idx]).max() <= tol * scale, (mode, r)
+
+
+def test_oracle_first_evaluation_and_drift_at_config2_size_vs_reference_ops():
+    """g17 (N = 65 536, FLOAT64 mode, fp32 initial conditions, zero velocities): the first force evaluation of 2048
+    sampled rows and the positions after the opening kick + drift, against the reference's own torch expressions
+    evaluated on row blocks (make_golden.py g17).  The full step and the energies need every row's force: GPU test."""
+    import torch
+    g = load_golden("g17_step_n65536.npz")
+    pos = load_golden("g16_bins_n65536_rows.npz")["pos"]
+    mass = np.ones(pos.shape[0], np.float32)
+    rows = g["rows"]
+    scale = np.abs(g["acc0"]).max()
+    for i0 in range(0, len(rows), 256):                      # the oracle evaluates contiguous row ranges
+        for r in rows[i0:i0 + 8]:                            # a few rows per block keep this a seconds-long test
+            got, _ = O.accelerations_rows(pos, mass, "float64", int(r), int(r) + 1)
+            idx = int(np.where(rows == r)[0][0])
+            assert got.dtype == np.float64
+            assert np.abs(got[0] - g["acc0"][idx]).max() <= 1e-13 * scale
+            v_half = 0.0 + got[0] * (0.01 / 2)
+            x1 = pos[r].astype(np.float64) + v_half * 0.01
+            assert np.abs(x1 - g["pos1"][idx]).max() <= 1e-15 * np.abs(g["pos1"]).max()
