@@ -751,6 +751,49 @@ def g17():
     print("G17", e0, e1, acc.dtype, pos1.dtype)
 
 
+def g18():
+    """Config 3's real size, INT8 / INT4 end to end: the forces of EVERY row at N = 65 536 through the reference's
+    expressions on row blocks (the hook sees blocks carrying the global bounds: every block is given the diagonal
+    value and the farthest pair's r2 as two extra entries of an extra row -- elementwise functions do not care), then
+    the reference's own quantize_force on the full (N, 2) tensor: fmin / fmax and the force bins.  Stored: the force
+    grid's bounds, the histogram of the force bins, and bins + values of 4096 sampled rows."""
+    n = 65536
+    g16_ = np.load(os.path.join(OUT, "g16_bins_n65536_rows.npz"))
+    pos = torch.from_numpy(g16_["pos"]).clone()
+    masses = torch.ones(n)
+    G, eps2 = 0.001, 0.1 ** 2
+    r2max = float(g16_["r2max"])
+    out = dict(rows=np.sort(np.random.default_rng(18).choice(n, 4096, replace=False)))
+    for mode in (PrecisionMode.INT8_SIM, PrecisionMode.INT4_SIM):
+        levels = 256 if mode == PrecisionMode.INT8_SIM else 16
+        acc = []
+        for i0 in range(0, n, 256):
+            rows = torch.arange(i0, min(i0 + 256, n))
+            diff = pos.unsqueeze(0) - pos[rows].unsqueeze(1)
+            dist_sq = (diff ** 2).sum(dim=-1) + eps2
+            # one extra row holding the global extremes, so that the hook's min / max are the full tensor's
+            extra = torch.full((1, n), float(dist_sq[0, rows[0]]))                 # the diagonal value (r2 = eps2)
+            extra[0, 0] = r2max
+            qd = ref_quant.quantize_distance_squared(torch.cat([dist_sq, extra.to(dist_sq.dtype)]), mode)[:-1]
+            ff = G / (qd ** 1.5)
+            ff = ff * masses.unsqueeze(0)
+            eye_rows = torch.zeros(len(rows), n)
+            eye_rows[torch.arange(len(rows)), rows] = 1.0
+            ff = ff * (1 - eye_rows)
+            acc.append((ff.unsqueeze(-1) * diff).sum(dim=1))
+        acc = torch.cat(acc)
+        q = ref_quant.quantize_force(acc.clone(), mode)
+        fk, fmin, fmax = lin_bins(acc, levels, q)
+        tag = mode.value
+        out[f"{tag}/fmin"], out[f"{tag}/fmax"] = fmin, fmax
+        out[f"{tag}/fhist"] = np.bincount(fk.ravel(), minlength=levels).astype(np.int64)
+        out[f"{tag}/fbins_rows"] = fk.astype(np.int16)[out["rows"]]
+        out[f"{tag}/acc_rows"] = npy(q.double())[out["rows"]]
+        out[f"{tag}/pre_rows"] = npy(acc.double())[out["rows"]]
+        print("G18", tag, fmin, fmax)
+    np.savez_compressed(os.path.join(OUT, "g18_force_quant_n65536.npz"), **out)
+
+
 def g15():
     """Mixed / unusual dtype combinations through the stock class (quantization.py:58-69 is dtype-polymorphic,
     simulation.py:105 promotes through the mass product)."""
@@ -826,6 +869,6 @@ def g14():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     for w in which:
         globals()[w]()

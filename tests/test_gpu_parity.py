@@ -1409,6 +1409,34 @@ def test_config2_full_size_step_and_energies_vs_reference_ops(nb):
     assert abs(sim.get_potential_energy() - g["e1"][1]) <= 1e-12 * abs(g["e1"][1])
 
 
+@pytest.mark.parametrize("mode", ["int8_sim", "int4_sim"])
+def test_config3_full_size_force_quantisation_vs_reference_ops(nb, mode):
+    """g18: INT8 / INT4 end to end at BASELINE config 3's real size -- the forces of every row at N = 65 536 from the
+    reference's torch expressions on row blocks, then the reference's own quantize_force on the full (N, 2) tensor
+    (tests/golden/make_golden.py g18).  The engine's force grid (fmin / fmax) to fp32 accuracy, and on 4096 sampled
+    rows the force bins: a summed force that sits on a rounding boundary of the grid may land in the neighbouring bin
+    (SURVEY.md section 7 hard part 2) -- at most a handful of the 8192 values, never further than one bin."""
+    g = load_golden("g18_force_quant_n65536.npz")
+    pos = torch.from_numpy(load_golden("g16_bins_n65536_rows.npz")["pos"])
+    n = pos.shape[0]
+    levels = 256 if mode == "int8_sim" else 16
+    sim = nb.GalaxySimulation(pos, torch.zeros_like(pos), torch.ones(n), precision_mode=nb.PrecisionMode(mode))
+    dbg = sim.quant_debug()
+    fmin, fmax = float(g[f"{mode}/fmin"]), float(g[f"{mode}/fmax"])
+    assert abs(dbg["fmin"] - fmin) <= 2e-6 * abs(fmin) and abs(dbg["fmax"] - fmax) <= 2e-6 * abs(fmax)
+    rows = g["rows"]
+    acc = sim.accelerations.numpy()[rows].astype(np.float64)
+    step = (fmax - fmin) / (levels - 1)
+    bins = np.rint((acc - dbg["fmin"]) / (dbg["fmax"] - dbg["fmin"]) * (levels - 1)).astype(np.int64)
+    ref_bins = g[f"{mode}/fbins_rows"].astype(np.int64)
+    flips = int((bins != ref_bins).sum())
+    assert np.abs(bins - ref_bins).max() <= 1
+    assert flips <= 8, flips
+    assert np.abs(acc - g[f"{mode}/acc_rows"]).max() <= 1.01 * step
+    same = bins == ref_bins
+    assert np.abs(acc[same] - g[f"{mode}/acc_rows"][same]).max() <= 2e-6 * max(abs(fmin), abs(fmax))
+
+
 def test_config3_full_size_bins_vs_reference_rows(nb):
     """g16: BASELINE config 3 at its real size, distance bins pinned to the REFERENCE itself -- six target rows at
     N = 65 536 (among them a row of the farthest pair, so the row block carries the global lmin / lmax) binned by the

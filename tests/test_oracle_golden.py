@@ -555,3 +555,16 @@ def test_oracle_first_evaluation_and_drift_at_config2_size_vs_reference_ops():
             v_half = 0.0 + got[0] * (0.01 / 2)
             x1 = pos[r].astype(np.float64) + v_half * 0.01
             assert np.abs(x1 - g["pos1"][idx]).max() <= 1e-15 * np.abs(g["pos1"]).max()
+
+
+def test_oracle_prequant_forces_at_config3_size_vs_reference_ops():
+    """g18: the forces BEFORE quantize_force of two sampled rows at N = 65 536 in INT8 mode (reference's torch
+    expressions on row blocks with the global grid bounds) against the oracle; the full force grid is a GPU test."""
+    g = load_golden("g18_force_quant_n65536.npz")
+    pos = load_golden("g16_bins_n65536_rows.npz")["pos"]
+    mass = np.ones(pos.shape[0], np.float32)
+    scale = np.abs(g["int8_sim/pre_rows"]).max()
+    for idx in (0, 2047):
+        r = int(g["rows"][idx])
+        got, _ = O.accelerations_rows(pos, mass, "int8_sim", r, r + 1)
+        assert np.abs(got[0].astype(np.float64) - g["int8_sim/pre_rows"][idx]).max() <= 2e-6 * scale
