@@ -794,6 +794,41 @@ def g18():
     np.savez_compressed(os.path.join(OUT, "g18_force_quant_n65536.npz"), **out)
 
 
+def g19_positions(n):
+    """Host-independent initial conditions for the big configurations: numpy's PCG64 stream and one multiply-add (no
+    transcendental, whose last bit depends on the host's vector ISA) -- tests regenerate them instead of loading them."""
+    return ((np.random.default_rng(1900 + n).random((n, 2), dtype=np.float32) - np.float32(0.5)) * np.float32(40.0)).astype(np.float32)
+
+
+def g19():
+    """BASELINE configs 4 / 5 at their real sizes (N = 262 144 and 1 048 576, FLOAT32 mode): the accelerations of 64
+    sampled rows from the reference's torch expressions on row blocks (simulation.py:83-112; FLOAT32 needs no global
+    pass).  Uniform square of stars, unit masses."""
+    out = {}
+    for n in (262144, 1048576):
+        pos = torch.from_numpy(g19_positions(n))
+        rows_all = np.sort(np.random.default_rng(19).choice(n, 64, replace=False))
+        masses = torch.ones(n)
+        acc = []
+        for b in range(0, 64, 16):
+            rows = torch.from_numpy(rows_all[b:b + 16])
+            diff = pos.unsqueeze(0) - pos[rows].unsqueeze(1)
+            dist_sq = (diff ** 2).sum(dim=-1) + 0.1 ** 2
+            qd = ref_quant.quantize_distance_squared(dist_sq, PrecisionMode.FLOAT32)
+            ff = 0.001 / (qd ** 1.5)
+            ff = ff * masses.unsqueeze(0)
+            eye_rows = torch.zeros(len(rows), n)
+            eye_rows[torch.arange(len(rows)), rows] = 1.0
+            ff = ff * (1 - eye_rows)
+            acc.append((ff.unsqueeze(-1) * diff).sum(dim=1))
+        acc = torch.cat(acc)
+        out[f"n{n}/rows"] = rows_all
+        out[f"n{n}/acc_rows"] = npy(acc.double())
+        out[f"n{n}/acc_dtype"] = np.array(str(acc.dtype))
+        print("G19", n, acc.dtype, float(acc.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "g19_big_n_rows.npz"), **out)
+
+
 def g15():
     """Mixed / unusual dtype combinations through the stock class (quantization.py:58-69 is dtype-polymorphic,
     simulation.py:105 promotes through the mass product)."""
@@ -869,6 +904,6 @@ def g14():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
     for w in which:
         globals()[w]()

@@ -699,6 +699,22 @@ def test_baseline_config_4_5_sizes_fp32(nb, n):
         assert relerr(sum(parts), s.accelerations.numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("n", [262144, 1048576])
+def test_baseline_config_4_5_sizes_vs_reference_ops(nb, n):
+    """g19: BASELINE configs 4 / 5 at their real sizes against the reference's arithmetic: FLOAT32 accelerations of 64
+    sampled rows from the reference's torch expressions on row blocks (tests/golden/make_golden.py g19).  The initial
+    conditions are regenerated here bit for bit (numpy PCG64 stream and one multiply-add: host-independent)."""
+    g = load_golden("g19_big_n_rows.npz")
+    pos = ((np.random.default_rng(1900 + n).random((n, 2), dtype=np.float32) - np.float32(0.5)) * np.float32(40.0)).astype(np.float32)
+    sim = nb.GalaxySimulation(T(pos), torch.zeros(n, 2), torch.ones(n), precision_mode=nb.PrecisionMode.FLOAT32)
+    assert sim.force_kernel_name() == "force_sym_kernel<float"
+    acc = sim.accelerations
+    assert str(acc.dtype) == str(g[f"n{n}/acc_dtype"])
+    got = acc.numpy()[g[f"n{n}/rows"]].astype(np.float64)
+    ref = g[f"n{n}/acc_rows"]
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+
+
 @pytest.mark.parametrize("mode", ["int8_sim", "int4_sim"])
 def test_grid_modes_pruned_max_r2_edge_cases(nb, mode):
     """The pruned max-r2 search (exact by construction) on awkward clouds: a far outlier, collinear
