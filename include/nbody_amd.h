@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 2
+#define NB_ABI_VERSION 3
 
 typedef enum nb_status {
     NB_OK = 0,
@@ -145,6 +145,25 @@ int nb_energy(nb_sim *s, double *kinetic, double *potential);
 int nb_quant_debug(nb_sim *s, double info[8], int16_t *d2bins, int16_t *fbins);
 /* The same distance-bin indices for target rows [i0, i1) only (host, (i1-i0)*n int16): sizes where n*n is out of reach. */
 int nb_quant_bins_rows(nb_sim *s, int32_t i0, int32_t i1, int16_t *d2bins);
+/* Quant-bin assignments (the index round(normalized * (levels - 1)) of quantization.py:119-121) read out of the
+ * PRODUCTION pair loop itself.  The two calls above walk the exact threshold tables in a kernel of their own; this one
+ * runs the evaluation once more on the current positions with the very kernel templates the force path launches,
+ * instantiated with an integer read-out at the point where each pair's bin is decided (table-free estimate, wave
+ * ballot, threshold fallback, uniform / general-mass kernels, packed and scalar sweeps, the one-launch small-system
+ * kernel), and returns per particle p (host arrays of n int64):
+ *     sum_k[p]  = sum over all q of k(p, q)
+ *     sum_kw[p] = sum over all q of k(p, q) * ((q mod 65521) + 1)
+ * (q = p included: the reference's N x N bin matrix holds k = 0 on the diagonal).  Integer sums: exact, independent
+ * of the summation order, comparable bit for bit with the same sums over a row of the reference's bin matrix.
+ * which: 0 = the path the last evaluation / step took (nb_force_kernel_name), 1 = the tiled evaluation path of
+ * nb_compute_accelerations, 2 = the one-launch small-system step kernel.
+ * info (may be NULL): [0] path taken (1 pair-symmetric tiles, 2 one-sided tiles, 3 small-system kernel), [1] targets
+ * per lane (path 1) / lanes per target (path 3), [2] 1 if the uniform-mass packed kernel did the work, [3] 1 if the
+ * tables enabled the table-free pair path, [4] pair evaluations binned by the table-free estimate alone, [5] pair
+ * evaluations binned through a threshold table, [6] grid levels.  Degenerate grids (values pass through, no bins),
+ * the generic per-pair path and handles with a communicator return NB_ERR_UNSUPPORTED.  The forces are recomputed
+ * (same values); velocities and positions are not touched. */
+int nb_quant_bin_sums(nb_sim *s, int32_t which, int64_t *sum_k, int64_t *sum_kw, double info[8]);
 
 /* ---- tensor-level hooks (quantization.py module functions used by override subclasses) -- */
 
@@ -207,6 +226,10 @@ int nb_metrics_tensors(int device, const void *pos, const void *vel, const void 
 int nb_comm_unique_id(void *id_out, int32_t *id_bytes /* in: capacity, out: size */);
 int nb_comm_init(nb_sim *s, const void *id /* NULL: attach the existing process communicator */, int32_t id_bytes);
 int nb_comm_ready(void);      /* ranks of the process communicator, 0 when there is none */
+/* What the process communicator is (for the caller's records): info = {ranks, rank, device, 1 if direct-only (no RCCL),
+ * ncclCommCount() of the RCCL communicator (-1: none), state of the direct all-reduce (0 none, 1 attached, 2 enabled),
+ * its rank count, communicator generation (handles attached to an older generation fail with NB_ERR_COMM)}. */
+int nb_comm_info(int32_t info[8]);
 int nb_comm_quiesce(void);    /* first half of a shutdown: wait for this process's device work (then: a barrier of the
                                * host transport, so that no rank frees buffers a peer still reads; then nb_comm_shutdown) */
 int nb_comm_shutdown(void);

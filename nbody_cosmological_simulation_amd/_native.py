@@ -27,7 +27,7 @@ MODE_CODES = {
 EXPORTS = [
     "nb_create", "nb_destroy", "nb_set_params", "nb_set_state", "nb_get_state", "nb_state_dtypes",
     "nb_set_accelerations", "nb_compute_accelerations", "nb_step", "nb_kick_drift", "nb_kick",
-    "nb_energy", "nb_quant_debug", "nb_quant_bins_rows", "nb_quantize_distance_squared", "nb_quantize_force",
+    "nb_energy", "nb_quant_debug", "nb_quant_bins_rows", "nb_quant_bin_sums", "nb_comm_info", "nb_quantize_distance_squared", "nb_quantize_force",
     "nb_grid_quantize", "nb_grid_quantize_safe", "nb_comm_unique_id", "nb_comm_init", "nb_comm_ready",
     "nb_comm_shutdown", "nb_comm_quiesce", "nb_comm_p2p_export", "nb_comm_p2p_import", "nb_comm_p2p_selftest",
     "nb_comm_p2p_enable", "nb_comm_p2p_state", "nb_comm_p2p_allreduce", "nb_comm_allreduce_time", "nb_comm_p2p_virtual_test", "nb_plan_debug", "nb_set_hook_stream", "nb_metrics", "nb_metrics_tensors",
@@ -80,6 +80,8 @@ def lib():
         "nb_energy": ([vp, pdbl, pdbl], C.c_int),
         "nb_quant_debug": ([vp, pdbl, vp, vp], C.c_int),
         "nb_quant_bins_rows": ([vp, i32, i32, vp], C.c_int),
+        "nb_quant_bin_sums": ([vp, i32, vp, vp, pdbl], C.c_int),
+        "nb_comm_info": ([pi32], C.c_int),
         "nb_quantize_distance_squared": ([C.c_int, vp, vp, i64, C.c_int, C.c_int, C.c_int, dbl, C.c_int, pi32], C.c_int),
         "nb_quantize_force": ([C.c_int, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, pi32], C.c_int),
         "nb_grid_quantize": ([C.c_int, vp, vp, i64, C.c_int, C.c_int, C.c_int], C.c_int),

@@ -192,11 +192,13 @@ force_f64_kernel(const double *__restrict__ pos, const double *__restrict__ mass
 // ------------------------------------------------------------------------------------------
 // fp32 state (FLOAT32 / BFLOAT16 / FLOAT16 / INT8 / INT4 / CUSTOM modes)
 // ------------------------------------------------------------------------------------------
-template <int D, int R, int HOOK, int PA = NB_F32>
+// BINS: the same body with the quant-bin read-out (per-target integer checksums s1 = sum_j k, s2 = sum_j k ((j mod
+// 65521) + 1), see nb_force_sym_kernel.h BinDbg), added to bin_out = {s1[n], s2[n], {0, table pairs}} with atomics.
+template <int D, int R, int HOOK, int PA = NB_F32, bool BINS = false>
 __global__ void __launch_bounds__(NB_BLOCK)
 force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
                  double *__restrict__ partial, ForceGeom g, float G, float eps2,
-                 const GridTables *__restrict__ tab, int lp)
+                 const GridTables *__restrict__ tab, int lp, unsigned long long *__restrict__ bin_out)
 {
     __shared__ float sj[D + 1][NB_TJ];
     extern __shared__ float s_tables[];        // grid hook: thr[lp + 1], lut[lp + 1] (nb_lut_lds_bytes)
@@ -222,6 +224,7 @@ force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
 
     float xi[R][D];
     double acc[R][D];
+    long long b1[BINS ? R : 1], b2[BINS ? R : 1], bcount = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int i = ibase + r * NB_BLOCK + tid;
@@ -231,6 +234,7 @@ force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
             xi[r][k] = pos[(size_t)i * D + k];
             acc[r][k] = 0.0;
         }
+        if constexpr (BINS) b1[r] = b2[r] = 0;
     }
 
     const int j_lo = g.j_begin + blockIdx.y * g.chunk_len;
@@ -279,6 +283,11 @@ force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
                         const int kb = use_est ? grid_bin_floor_estimate(s_thr, r2, est_a, est_b, est_kmax)
                                                : grid_bin_lookup(s_thr, r2, lp);
                         wq = s_lut[kb];
+                        if constexpr (BINS) {
+                            b1[r] += kb;
+                            b2[r] += (long long)kb * ((jt + jj) % 65521 + 1);
+                            ++bcount;
+                        }
                     } else {
                         const float q = (r2 < 0.01f) ? 0.01f : r2;     // clamp keeps NaN
                         wq = inv_r3_f32(q) * G;
@@ -310,7 +319,18 @@ force_f32_kernel(const float *__restrict__ pos, const float *__restrict__ mass,
         if (i < g.n) {
 #pragma unroll
             for (int k = 0; k < D; ++k) out[(size_t)i * D + k] = acc[r][k];
+            if constexpr (BINS) {
+                atomicAdd(&bin_out[i], (unsigned long long)b1[r]);
+                atomicAdd(&bin_out[(size_t)g.n + i], (unsigned long long)b2[r]);
+            }
         }
+    }
+    if constexpr (BINS) {
+        // clamped duplicate targets (i >= n) counted pairs too: report only this thread's live ones
+        int live = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) live += (ibase + r * NB_BLOCK + tid < g.n) ? 1 : 0;
+        atomicAdd(&bin_out[2 * (size_t)g.n + 1], (unsigned long long)(bcount / R * live));
     }
 }
 
@@ -984,24 +1004,30 @@ hipError_t nb_launch_force_f64(const double *pos, const double *mass, double *pa
 
 hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *partial, const ForceGeom &g,
                                int dim, int hook, int pa, float G, float eps2, const GridTables *tab, int levels,
-                               hipStream_t st)
+                               hipStream_t st, unsigned long long *bin_out)
 {
     const int lp = hook == HOOK_GRID ? nb_lut_pad(levels) : 0;
     const size_t lds = hook == HOOK_GRID ? nb_lut_lds_bytes(levels) : 0;
     // small systems are parallelism-bound: one target per thread doubles the workgroups (like the fp64 kernel)
     const int r = g.n <= 8192 ? 1 : R_F32;
     const dim3 grid((g.n + NB_BLOCK * r - 1) / (NB_BLOCK * r), g.nchunks);
-#define NB_F32K(DD, HH, PP)                                                                                              \
+#define NB_F32KB(DD, HH, PP, BB)                                                                                         \
     do {                                                                                                                 \
         if (r == 1)                                                                                                      \
-            hipLaunchKernelGGL((force_f32_kernel<DD, 1, HH, PP>), grid, dim3(NB_BLOCK), lds, st, pos, mass, partial, g,  \
-                               G, eps2, tab, lp);                                                                        \
+            hipLaunchKernelGGL((force_f32_kernel<DD, 1, HH, PP, BB>), grid, dim3(NB_BLOCK), lds, st, pos, mass, partial, g, \
+                               G, eps2, tab, lp, bin_out);                                                               \
         else                                                                                                             \
-            hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HH, PP>), grid, dim3(NB_BLOCK), lds, st, pos, mass, partial, \
-                               g, G, eps2, tab, lp);                                                                     \
+            hipLaunchKernelGGL((force_f32_kernel<DD, R_F32, HH, PP, BB>), grid, dim3(NB_BLOCK), lds, st, pos, mass, partial, \
+                               g, G, eps2, tab, lp, bin_out);                                                            \
     } while (0)
+#define NB_F32K(DD, HH, PP) NB_F32KB(DD, HH, PP, false)
     return dispatch_dim(dim, [&](auto D) {
         constexpr int DD = decltype(D)::value;
+        if (bin_out) {           // bin read-out of the grid hook (nb_quant_bin_sums): same body, BINS = true
+            if (hook != HOOK_GRID || pa != NB_F32) return hipErrorInvalidValue;
+            NB_F32KB(DD, HOOK_GRID, NB_F32, true);
+            return hipGetLastError();
+        }
         if (pa != NB_F32) {
             // half-typed state: cast hooks only (a grid over a half tensor is not implemented)
             if (hook == HOOK_GRID) return hipErrorInvalidValue;
@@ -1026,6 +1052,7 @@ hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *part
         return hipGetLastError();
     });
 #undef NB_F32K
+#undef NB_F32KB
 }
 
 hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float eps2, GridTables *tab,

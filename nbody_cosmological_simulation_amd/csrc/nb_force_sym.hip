@@ -20,547 +20,9 @@
 //   LDS in a fixed order, so one column slab per super-row leaves the chip (4x less slab traffic
 //   than one per row).  Row sums go to per-(row, chunk) slots.  reduce_sym_kernel adds slots and
 //   slabs in a fixed order: no atomics, run-to-run bit-identical.
-#include "nb_device.h"
-#ifdef NB_GRID_R2_EXACT
-#define NB_GRID_R2_EXACT_V 1
-#else
-#define NB_GRID_R2_EXACT_V 0
-#endif
-
-#include <hip/hip_ext.h>
-
-#include <type_traits>
+#include "nb_force_sym_kernel.h"
 
 namespace {
-
-using namespace nbdev;
-
-template <typename T>
-__device__ __forceinline__ T rot1(T v, int addr);
-
-template <>
-__device__ __forceinline__ double rot1<double>(double v, int addr)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)(b & 0xffffffffll));
-    const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(b >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-template <>
-__device__ __forceinline__ float rot1<float>(float v, int addr)
-{
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
-}
-
-// q^(-3/2) without any mass factor.
-// fp64: v_rsq_f64 seed (2^-24) + second-order correction, see inv_r3_f64 in nb_force.hip.
-//       c15 / c1875 hold 1.5 and 1.875 in registers chosen by the caller: as literals the
-//       compiler re-materialises 1.5 with two v_mov per pair (v_fmac needs it in the destination).
-__device__ __forceinline__ double inv_r3_sym(double q, double c15, double c1875)
-{
-#ifdef NB_EXP_RSQ_F32
-    const double y0 = (double)__builtin_amdgcn_rsqf((float)q);   // experiment: fp32 seed via two converts
-#else
-    const double y0 = __builtin_amdgcn_rsq(q);
-#endif
-    const double y02 = y0 * y0;
-    const double e = __builtin_fma(-q, y02, 1.0);
-    const double v = y0 * y02;
-    const double c = __builtin_fma(e, c1875, c15);
-    const double ce = c * e;
-    return __builtin_fma(v, ce, v);
-}
-// fp32: v_rsq_f32 seed (1 ulp) + first-order correction of the cube: y0^3 (1 + 1.5 e), residual
-//       ~2 e^2 < 1e-13, leaving only the ~1.5 ulp of the three roundings.
-__device__ __forceinline__ float inv_r3_sym(float q, float c15, float)
-{
-    const float y0 = __builtin_amdgcn_rsqf(q);
-    const float y02 = y0 * y0;
-    const float e = __builtin_fmaf(-q, y02, 1.0f);
-    const float v = y0 * y02;
-    const float ve = v * e;
-    return __builtin_fmaf(ve, c15, v);
-}
-
-// Source slots per sweep: the whole tile (R) in 2-D; in 3-D four targets and four sources per lane do not fit
-// 128 VGPRs, so the source tile is swept in two halves of two slots (8 pairs per lane per rotation step
-// instead of the 4 of an R = 2 tiling).
-constexpr int sym_rj(int d, int r) { return (d == 3 && r == 4) ? 2 : r; }
-
-struct GridArgs {
-    const float *thr, *lut;
-    float est_a, est_b, gfac;
-    int lmax_bin;
-    int lp;                 // table size (power of two) for the binary-search fallback
-    // table-free path (GridTables::fast_ok): bin - kc = rint(centred estimate) when the estimate is further than
-    // sure_lim from a bin edge, scaled force factor = v_exp_f32((bin - kc) c1 + c0c)
-    float est_bc, sure_lim, c1, c0c, kcf;
-};
-// grid variants of the sweeps (template parameter EST): how a pair finds its force factor
-enum { GRID_SEARCH = 0,   // binary search over the thresholds (estimate unusable: very narrow grids)
-       GRID_EST = 2,      // floor(estimate) + one threshold compare + table value: two dependent LDS reads
-       GRID_FAST = 3,     // table-free (see GridArgs); falls back to GRID_EST for a wave with a pair near a bin edge
-       GRID_FAST_CLAMP = 4,   // ... with softening^2 below the grid's floor 0.01: estimates below bin 0 clamp to it
-       GRID_DEGENERATE = 5 }; // lmax - lmin < 1e-10: clamped values pass through (quantization.py:115-116)
-
-// One sweep of a target tile (R particles per lane) against RJ source slots: `nsteps` rotation steps (64 = all
-// lanes), R*RJ pairs per lane per step, J data rotating by one lane per step.  RJ = R covers the whole
-// source tile; D = 3 sweeps it in two halves (RJ = 2) to stay inside 128 VGPRs with R = 4 targets.
-// DIAG:    J is the target tile itself -> one-sided (each ordered pair once, mirrors dropped).
-// UNIFORM: all masses equal -> the mass factor is applied once to the finished sums
-//          (reduce_sym_kernel), saving both mass multiplies and the rotation of the masses.
-// HOOK:    precision hook applied to the fp32 r2 (HOOK_NONE for fp64); EST: grid bins by estimate.
-template <typename T, int D, int R, int RJ, bool DIAG, bool UNIFORM, int HOOK, int EST>
-__device__ __forceinline__ void sweep(const T (&xi)[R][D], const T (&gi)[R], T (&ai)[R][D], T (&xj)[RJ][D],
-                                      T (&gj)[RJ], T (&aj)[RJ][D], T eps2, int rot_addr, const GridArgs &ga,
-                                      int nsteps)
-{
-    T c15 = (T)1.5, c1875 = (T)1.875;
-    if constexpr (std::is_same_v<T, double>) asm volatile("" : "+v"(c15), "+s"(c1875));
-#pragma unroll 1
-    for (int s = 0; s < nsteps; ++s) {
-        // source slot outermost: once all targets have met source rj its data and accumulator are
-        // final for this step, so their rotation is issued at once and overlaps the remaining slots
-#pragma unroll
-        for (int rj = 0; rj < RJ; ++rj) {
-#pragma unroll
-            for (int ri = 0; ri < R; ++ri) {
-                T d[D];
-                T w;
-                if constexpr (std::is_same_v<T, double>) {
-                    double q;
-                    if (HOOK == HOOK_F32PAIR) {
-                        // FLOAT64 mode on fp32-typed positions (first evaluation): diff and
-                        // r2 in fp32 in the reference's op order, everything after the hook in fp64
-                        float df[D];
-#pragma unroll
-                        for (int k = 0; k < D; ++k) {
-                            df[k] = __fsub_rn((float)xj[rj][k], (float)xi[ri][k]);
-                            d[k] = (double)df[k];
-                        }
-                        q = (double)r2_f32_exact<D>(df, ga.gfac);       // gfac carries eps2 as fp32 here
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < D; ++k) d[k] = xj[rj][k] - xi[ri][k];
-                        q = __builtin_fma(d[D - 1], d[D - 1], eps2);
-#pragma unroll
-                        for (int k = D - 2; k >= 0; --k) q = __builtin_fma(d[k], d[k], q);
-                    }
-                    w = inv_r3_sym(q, c15, c1875);
-                } else {
-                    // reference op order, one rounding per op, no FMA (bit-identical r2)
-#pragma unroll
-                    for (int k = 0; k < D; ++k) d[k] = __fsub_rn(xj[rj][k], xi[ri][k]);
-                    float r2;
-#ifndef NB_GRID_R2_EXACT
-                    if (HOOK == HOOK_GRID && (EST == GRID_FAST || EST == GRID_FAST_CLAMP)) {
-                        // the ESTIMATE may take r2 from fused multiply-adds (D ops instead of 2 D; within 4 ulp of the
-                        // reference's r2 = 7e-7 * est_a bins, which sure_lim allows for): a pair far from every bin edge
-                        // has the same bin either way, and the rare wave with a pair near an edge recomputes the
-                        // reference's r2 bit for bit before it consults the thresholds
-                        r2 = __builtin_fmaf(d[D - 1], d[D - 1], eps2);
-#pragma unroll
-                        for (int k = D - 2; k >= 0; --k) r2 = __builtin_fmaf(d[k], d[k], r2);
-                    } else
-#endif
-                    {
-                        r2 = __fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1]));
-                        if (D == 3) r2 = __fadd_rn(r2, __fmul_rn(d[2], d[2]));
-                        r2 = __fadd_rn(r2, eps2);
-                    }
-                    if (HOOK == HOOK_GRID) {
-                        if (EST == GRID_DEGENERATE) {
-                            w = inv_r3_sym((r2 < 0.01f) ? 0.01f : r2, c15, c1875) * ga.gfac;
-                        } else if (EST == GRID_FAST || EST == GRID_FAST_CLAMP) {
-                            // table-free unless one of the wave's 64 pairs sits near a bin edge (see sweep_pk)
-                            const float ne = __builtin_fmaf(__builtin_amdgcn_logf(r2), ga.est_a, ga.est_bc);
-                            float kf = __builtin_rintf(ne);
-                            const float dev = __builtin_fabsf(ne - kf);
-                            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(dev <= ga.sure_lim)) != 0ull, 0)) {
-                                float r2e = __fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1]));
-                                if (D == 3) r2e = __fadd_rn(r2e, __fmul_rn(d[2], d[2]));
-                                r2e = __fadd_rn(r2e, eps2);
-                                w = ga.lut[grid_bin_floor_estimate(ga.thr, r2e, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
-                            } else {
-                                if (EST == GRID_FAST_CLAMP) kf = __builtin_amdgcn_fmed3f(kf, -ga.kcf, 1e30f);
-                                w = __builtin_amdgcn_exp2f(__builtin_fmaf(kf, ga.c1, ga.c0c));
-                            }
-                        } else if (EST == GRID_EST) {
-                            w = ga.lut[grid_bin_floor_estimate(ga.thr, r2, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
-                        } else {
-                            w = ga.lut[grid_bin_lookup(ga.thr, r2, ga.lp)];   // (1/q^1.5)*G
-                        }
-                    } else {
-                        float q = r2;
-                        if (HOOK == HOOK_BF16) q = (float)(__bf16)r2;
-                        if (HOOK == HOOK_F16) q = (float)(_Float16)r2;
-                        w = inv_r3_sym(q, c15, c1875);
-                        // fp16 overflow: q = +inf -> pow = inf -> 1/inf = 0 upstream (rsq-based form gives NaN)
-                        if (HOOK == HOOK_F16) w = (q == __builtin_inff()) ? 0.0f : w;
-                    }
-                }
-                const T wj = UNIFORM ? w : w * gj[rj];
-#pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    if constexpr (std::is_same_v<T, double>) ai[ri][k] = __builtin_fma(wj, d[k], ai[ri][k]);
-                    else ai[ri][k] = __builtin_fmaf(wj, d[k], ai[ri][k]);
-                }
-                if (!DIAG) {
-                    const T wi = UNIFORM ? w : w * gi[ri];
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        if constexpr (std::is_same_v<T, double>) aj[rj][k] = __builtin_fma(-wi, d[k], aj[rj][k]);
-                        else aj[rj][k] = __builtin_fmaf(-wi, d[k], aj[rj][k]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                xj[rj][k] = rot1<T>(xj[rj][k], rot_addr);
-                if (!DIAG) aj[rj][k] = rot1<T>(aj[rj][k], rot_addr);
-            }
-            if (!UNIFORM) gj[rj] = rot1<T>(gj[rj], rot_addr);
-        }
-    }
-}
-
-// fp32 sweep on packed pairs.  A lone wave issues one VALU instruction per ~4.6 cycles, i.e. half the
-// fp32 rate, so the scalar fp32 loop needs two ready waves at all times and loses ~25 % to stalls;
-// v_pk_{add,mul,fma}_f32 do two lanes' worth per issue.  Source slots (rj, rj+1) ride in the two halves
-// of a float2, so d, r2, the correction, the mass factors and both accumulations are packed; only
-// v_rsq_f32, the half-precision converts and the grid lookups stay per component.  Arithmetic is
-// identical to the scalar form (same operations, same order; -ffp-contract=off keeps r2 unfused).
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f2 rot1_f2(f2 v, int addr) { return f2{rot1<float>(v.x, addr), rot1<float>(v.y, addr)}; }
-
-template <int D, int R, int RJ, bool DIAG, bool UNIFORM, int HOOK, int EST>
-__device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&gi)[R], f2 (&ai2)[R][D],
-                                         f2 (&xj2)[RJ / 2][D], f2 (&gj2)[RJ / 2], f2 (&aj2)[RJ / 2][D], float eps2,
-                                         int rot_addr, const GridArgs &ga, int nsteps)
-{
-#ifdef NB_F32_CORR
-    const f2 c15 = {1.5f, 1.5f}, one = {1.0f, 1.0f};
-#endif
-    // table-free grid path: the two additive constants of its packed fmas live in VGPR pairs for the whole sweep
-    // (a packed op reads at most one SGPR pair: from SGPRs they cost a v_mov_b64 per use, 2 of ~23 VALU ops per unit)
-    f2 est_bc2 = {ga.est_bc, ga.est_bc}, c0c2 = {ga.c0c, ga.c0c};
-#ifndef NB_GRID_CONST_SGPR
-    if (HOOK == HOOK_GRID && (EST == GRID_FAST || EST == GRID_FAST_CLAMP)) asm volatile("" : "+v"(est_bc2), "+v"(c0c2));
-#endif
-#pragma unroll 1
-    for (int s = 0; s < nsteps; ++s) {
-#pragma unroll
-        for (int h = 0; h < RJ / 2; ++h) {
-#pragma unroll
-            for (int ri = 0; ri < R; ++ri) {
-                f2 d[D];
-#pragma unroll
-                for (int k = 0; k < D; ++k) d[k] = xj2[h][k] - xi[ri][k];
-                f2 r2;
-#ifndef NB_F32_R2_EXACT
-                if constexpr (HOOK == HOOK_NONE || (HOOK == HOOK_GRID && (EST == GRID_FAST || EST == GRID_FAST_CLAMP) && !NB_GRID_R2_EXACT_V)) {
-                    // grid modes, table-free path: only the ESTIMATE uses this r2 (see the scalar sweep above); the
-                    // fallback below recomputes the reference's r2.
-                    // FLOAT32 mode has no rounding DECISION hanging on r2 (no bins, no half-type cast), so r2 is built with
-                    // fused multiply-adds: D packed ops instead of 2 D, and closer to the exact r2 than the reference's
-                    // separately rounded sum (summed forces vs exact: rms 1.12e-8 against 1.21e-8 with the unfused form and
-                    // 1.51e-8 for the reference's own fp32 arithmetic; tests/tools/f32_accuracy.py).  0.581 -> 0.532 ms per
-                    // launch on the same box.  Every hook that DOES round r2 keeps the reference's r2 bit for bit, below.
-                    r2 = __builtin_elementwise_fma(d[D - 1], d[D - 1], f2{eps2, eps2});
-#pragma unroll
-                    for (int k = D - 2; k >= 0; --k) r2 = __builtin_elementwise_fma(d[k], d[k], r2);
-                } else
-#endif
-                {
-                    r2 = d[0] * d[0] + d[1] * d[1];         // one rounding per op (contraction is off): the reference's r2, bit for bit
-                    if constexpr (D == 3) r2 = r2 + d[2] * d[2];
-                    r2 = r2 + eps2;
-                }
-                f2 w;
-                if (HOOK == HOOK_GRID) {
-                    if (EST == GRID_DEGENERATE) {
-                        w.x = inv_r3_sym((r2.x < 0.01f) ? 0.01f : r2.x, 1.5f, 0.0f) * ga.gfac;
-                        w.y = inv_r3_sym((r2.y < 0.01f) ? 0.01f : r2.y, 1.5f, 0.0f) * ga.gfac;
-                    } else if (EST == GRID_FAST || EST == GRID_FAST_CLAMP) {
-                        // no table access for a wave whose 128 pairs all sit clear of the bin edges (the common case:
-                        // an edge zone is ~1e-4 of a bin wide); the estimate is the one grid_tables_kernel validated
-                        const f2 lg = {__builtin_amdgcn_logf(r2.x), __builtin_amdgcn_logf(r2.y)};
-                        const f2 ne = __builtin_elementwise_fma(lg, f2{ga.est_a, ga.est_a}, est_bc2);
-                        f2 kf = {__builtin_rintf(ne.x), __builtin_rintf(ne.y)};
-                        const f2 fr = ne - kf;
-                        const float dev = __builtin_fmaxf(__builtin_fabsf(fr.x), __builtin_fabsf(fr.y));
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(dev <= ga.sure_lim)) != 0ull, 0)) {   // also taken for NaN
-                            f2 r2e = d[0] * d[0] + d[1] * d[1];     // the reference's r2, bit for bit (one rounding per op)
-                            if constexpr (D == 3) r2e = r2e + d[2] * d[2];
-                            r2e = r2e + eps2;
-                            w.x = ga.lut[grid_bin_floor_estimate(ga.thr, r2e.x, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
-                            w.y = ga.lut[grid_bin_floor_estimate(ga.thr, r2e.y, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
-                        } else {
-                            if (EST == GRID_FAST_CLAMP)
-                                kf = f2{__builtin_amdgcn_fmed3f(kf.x, -ga.kcf, 1e30f), __builtin_amdgcn_fmed3f(kf.y, -ga.kcf, 1e30f)};
-                            const f2 th = __builtin_elementwise_fma(kf, f2{ga.c1, ga.c1}, c0c2);
-                            w = f2{__builtin_amdgcn_exp2f(th.x), __builtin_amdgcn_exp2f(th.y)};
-                        }
-                    } else if (EST == GRID_EST) {
-                        w.x = ga.lut[grid_bin_floor_estimate(ga.thr, r2.x, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
-                        w.y = ga.lut[grid_bin_floor_estimate(ga.thr, r2.y, ga.est_a, ga.est_b, ga.lmax_bin - 1)];
-                    } else {
-                        w.x = ga.lut[grid_bin_lookup(ga.thr, r2.x, ga.lp)];
-                        w.y = ga.lut[grid_bin_lookup(ga.thr, r2.y, ga.lp)];
-                    }
-                } else {
-                    if constexpr (HOOK == HOOK_BF16 || HOOK == HOOK_F16) {
-                        // BFLOAT16 / FLOAT16 hooks: q carries 8 / 11 significant bits, so the 1-ulp v_rsq_f32 cubed
-                        // (<= 3 ulp of fp32, 2e-7) is already four orders of magnitude below the hook's own rounding
-                        // of r2 -- no Newton correction.  That also serves fp16 overflow for free: q = +inf gives
-                        // v_rsq_f32 = 0, w = 0, which is what upstream's G / inf**1.5 yields (the corrected form would
-                        // produce inf * 0).  Packed conversion to the half type (v_cvt_pk_*; round to nearest even).
-                        f2 q;
-                        if constexpr (HOOK == HOOK_BF16) {
-                            typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-                            q = __builtin_convertvector(__builtin_convertvector(r2, b2), f2);
-                        } else {
-                            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                            q = __builtin_convertvector(__builtin_convertvector(r2, h2), f2);
-                        }
-                        const f2 y0 = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
-                        w = y0 * (y0 * y0);
-                    } else {
-                        // FLOAT32 hook: the 1-ulp v_rsq_f32 cubed, no Newton correction (round 2).  Measured against the
-                        // exact fp64 forces at N = 30 000 (tests/tools/f32_accuracy.py, relative to the force scale): the
-                        // reference's own fp32 arithmetic (its CPU restatement) max 1.05e-7 / rms 1.51e-8; this kernel WITH the
-                        // first-order correction 1.26e-7 / 1.61e-8, WITHOUT 1.23e-7 / 1.21e-8 -- the error of the summed
-                        // forces is set by the fp32 roundings of the differences, r2 and the products, not by the last
-                        // ulp of q^-3/2, so the three packed ops of the correction bought nothing (0.657 -> 0.556 ms per
-                        // launch at N = 65 536).  NB_F32_CORR restores it for A/B measurements.
-                        const f2 q = r2;
-                        const f2 y0 = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
-                        const f2 y02 = y0 * y0;
-#ifdef NB_F32_CORR
-                        const f2 e = __builtin_elementwise_fma(-q, y02, one);
-                        const f2 v = y0 * y02;
-                        const f2 ve = v * e;
-                        w = __builtin_elementwise_fma(ve, c15, v);
-#else
-                        w = y0 * y02;
-#endif
-                    }
-                }
-                const f2 wj = UNIFORM ? w : w * gj2[h];
-#pragma unroll
-                for (int k = 0; k < D; ++k) ai2[ri][k] = __builtin_elementwise_fma(wj, d[k], ai2[ri][k]);
-                if (!DIAG) {
-                    const f2 wi = UNIFORM ? w : w * gi[ri];
-#pragma unroll
-                    for (int k = 0; k < D; ++k) aj2[h][k] = __builtin_elementwise_fma(-wi, d[k], aj2[h][k]);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                xj2[h][k] = rot1_f2(xj2[h][k], rot_addr);
-                if (!DIAG) aj2[h][k] = rot1_f2(aj2[h][k], rot_addr);
-            }
-            if (!UNIFORM) gj2[h] = rot1_f2(gj2[h], rot_addr);
-        }
-    }
-}
-
-// T = double: FLOAT64 mode on fp64 state.  T = float: every fp32-state mode (HOOK selects it).
-// packed  [D+1][NP] of T : x, y, (z), mass factor (G*m, or m for HOOK_GRID whose LUT carries G);
-//                          padding particles sit far away (see pack_kernel).
-// rowslab [slot][D][B] fp64 (one target tile per workgroup slot), colslab [row][D][NP] of T.
-// <= 128 VGPRs: four waves per SIMD.  (Five waves -- 96 VGPRs -- were measured too: no gain at any
-// shard count, and the general-mass kernel starts to spill.)
-template <typename T, int D, int R, bool UNIFORM, int HOOK, int LPC = NB_LUT_MIN>
-__global__ void __launch_bounds__(NB_BLOCK, (HOOK == HOOK_GRID && LPC > NB_LUT_MIN) ? 3 : 4)
-force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work, double *__restrict__ rowslab,
-                 T *__restrict__ colslab, int np, T eps2, const GridTables *__restrict__ tab, float gfac, int gate)
-{
-    constexpr int B = 64 * R;
-    constexpr int RJ = sym_rj(D, R);            // source slots per sweep
-    constexpr int W = NB_BLOCK / 64;
-    constexpr bool F32 = std::is_same_v<T, float>;
-    __shared__ T s_aj[W][RJ][D][64];
-    // grid hook: threshold and LUT tables with compile-time offsets (a run-time table base costs an address add per
-    // lookup: +4..8 % on the INT8 / CUSTOM kernels).  LPC = 256 serves INT8 / INT4 / CUSTOM <= 256, LPC = NB_MAX_LUT
-    // the larger CUSTOM grids (33 KB: three workgroups per CU instead of four).
-    constexpr int lp = LPC;
-    __shared__ float s_thr[HOOK == HOOK_GRID ? LPC + 1 : 1];
-    __shared__ float s_lut[HOOK == HOOK_GRID ? LPC + 1 : 1];
-
-    const SymWork wk = work[blockIdx.x];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int I = wk.tile_i + wave;             // this wave's target tile (wave-uniform)
-    const int rot_addr = ((lane + 1) & 63) << 2;
-    GridArgs ga{s_thr, s_lut, 0.0f, 0.0f, gfac, 0, lp, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    bool use_est = false, fast = false, degenerate = false;
-    float gscale = gfac;      // uniform-mass grid kernel: factor applied to the finished sums (the common mass)
-    int mass_exp = 0;
-    if (HOOK == HOOK_GRID) {
-        const int levels = tab->levels;
-        // uniform-mass grid kernel (gate 1) and its general-mass stand-in (gate 2) are launched as a
-        // pair; the tables decide on the device which of the two does the work
-        const int ok = tab->uniform_ok;
-        if ((gate == 1 && !ok) || (gate == 2 && ok)) return;
-        // table-free pairs produce factors scaled by 2^-tm (GridTables): the table copies are scaled alike
-        // (exact: a power of two) and the power of two goes back in with the common mass
-        fast = tab->fast_ok != 0;
-        const int tm = fast ? tab->tm : 0;
-        mass_exp = UNIFORM ? 0 : tm;          // general masses: the power of two rides on the mass factors instead
-        for (int k = threadIdx.x; k <= lp; k += NB_BLOCK) {
-            // binary search pads with +inf; the estimate path needs the NaN sentinel at thr[levels]
-            s_thr[k] = (k <= levels) ? tab->thr[k] : __builtin_inff();
-            // uniform masses: padding particles (r2 >= 1e36) are caught by one more "bin" of weight 0
-            if (UNIFORM && k == levels) s_thr[k] = 1e35f;
-            s_lut[k] = (k < levels) ? ldexpf(tab->lut[k], -tm) : 0.0f;
-        }
-        degenerate = tab->degenerate != 0;
-        ga.est_a = tab->est_a;
-        ga.est_b = tab->est_b;
-        ga.lmax_bin = UNIFORM ? levels : levels - 1;
-        use_est = tab->use_est != 0;
-        ga.est_bc = tab->est_bc;
-        ga.sure_lim = tab->sure_lim;
-        ga.c1 = tab->c1;
-        ga.c0c = tab->c0c;
-        ga.kcf = (float)tab->kc;
-        gscale = ldexpf(gfac, tm);
-        __syncthreads();
-    }
-
-    T xi[R][D], gi[R];
-    double ai_sum[R][D];      // fp64 running sums over the whole chunk (fp32: folded per tile)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int p = I * B + r * 64 + lane;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            xi[r][k] = packed[(size_t)k * np + p];
-            ai_sum[r][k] = 0.0;
-        }
-        gi[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
-        if constexpr (F32 && HOOK == HOOK_GRID && !UNIFORM) gi[r] = ldexpf(gi[r], mass_exp);
-    }
-
-    for (int J = wk.jt_begin; J < wk.jt_end; ++J) {     // all four waves take the same source tile
-      for (int half = 0; half < R / RJ; ++half) {       // ... in R / RJ parts of RJ source slots each
-        const int hs = half * RJ;                       // first source slot of this part
-        T aj[RJ][D];
-#pragma unroll
-        for (int r = 0; r < RJ; ++r)
-#pragma unroll
-            for (int k = 0; k < D; ++k) aj[r][k] = (T)0;
-        if (J >= I) {                                   // wave-uniform; tiles below the diagonal belong to other rows
-            const bool diag = (J == I);
-            // fp32 modes: source slots (2h, 2h+1) packed in float2 halves (sweep_pk).  The general-mass grid kernel
-            // keeps the scalar loop (its packed form needs more than 128 VGPRs: measured 1.50 vs 1.24 ms per launch
-            // at N = 65536 with the spills inside the pair loop); the uniform-mass one always has a usable estimate
-            // (GridTables::uniform_ok gates it).
-            constexpr bool use_packed = F32 && (RJ % 2 == 0) && (HOOK != HOOK_GRID || UNIFORM);
-            if constexpr (use_packed) {
-                f2 xj2[RJ / 2][D], gj2[RJ / 2], aj2[RJ / 2][D], ai2[R][D];
-#pragma unroll
-                for (int h = 0; h < RJ / 2; ++h) {
-                    // a split sweep starts s_begin rotation steps in: lane l meets particle (l + s_begin) first
-                    const int p0 = J * B + (hs + 2 * h) * 64 + ((lane + wk.s_begin) & 63);
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        xj2[h][k] = f2{packed[(size_t)k * np + p0], packed[(size_t)k * np + p0 + 64]};
-                        aj2[h][k] = f2{0.0f, 0.0f};
-                    }
-                    gj2[h] = UNIFORM ? f2{1.0f, 1.0f} : f2{packed[(size_t)D * np + p0], packed[(size_t)D * np + p0 + 64]};
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int k = 0; k < D; ++k) ai2[r][k] = f2{0.0f, 0.0f};
-#define NB_SWEEP_PK(EE)                                                                                                   \
-    do {                                                                                                                 \
-        if (diag) sweep_pk<D, R, RJ, true, UNIFORM, HOOK, EE>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count); \
-        else sweep_pk<D, R, RJ, false, UNIFORM, HOOK, EE>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count);     \
-    } while (0)
-                if (HOOK == HOOK_GRID && fast) {
-                    if (eps2 < 0.01f) NB_SWEEP_PK(GRID_FAST_CLAMP);
-                    else NB_SWEEP_PK(GRID_FAST);
-                } else if (HOOK == HOOK_GRID) {
-                    NB_SWEEP_PK(GRID_EST);           // only reached with a usable estimate
-                } else {
-                    NB_SWEEP_PK(0);
-                }
-#undef NB_SWEEP_PK
-#pragma unroll
-                for (int h = 0; h < RJ / 2; ++h)
-#pragma unroll
-                    for (int k = 0; k < D; ++k) { aj[2 * h][k] = aj2[h][k].x; aj[2 * h + 1][k] = aj2[h][k].y; }
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int k = 0; k < D; ++k) ai_sum[r][k] += (double)(ai2[r][k].x + ai2[r][k].y);
-            } else {
-                T xj[RJ][D], gj[RJ], ai[R][D];
-#pragma unroll
-                for (int r = 0; r < RJ; ++r) {
-                    const int p = J * B + (hs + r) * 64 + ((lane + wk.s_begin) & 63);
-#pragma unroll
-                    for (int k = 0; k < D; ++k) xj[r][k] = packed[(size_t)k * np + p];
-                    gj[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
-                    if constexpr (F32 && HOOK == HOOK_GRID && !UNIFORM) gj[r] = ldexpf(gj[r], mass_exp);
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int k = 0; k < D; ++k) ai[r][k] = F32 ? (T)0 : (T)ai_sum[r][k];
-#define NB_SWEEP(EE)                                                                                                  \
-    do {                                                                                                                 \
-        if (diag) sweep<T, D, R, RJ, true, UNIFORM, HOOK, EE>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);     \
-        else sweep<T, D, R, RJ, false, UNIFORM, HOOK, EE>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count);         \
-    } while (0)
-                if (HOOK == HOOK_GRID && degenerate) NB_SWEEP(GRID_DEGENERATE);
-                else if (HOOK == HOOK_GRID && fast && eps2 < (T)0.01) NB_SWEEP(GRID_FAST_CLAMP);
-                else if (HOOK == HOOK_GRID && fast) NB_SWEEP(GRID_FAST);
-                else if (HOOK == HOOK_GRID && use_est) NB_SWEEP(GRID_EST);
-                else NB_SWEEP(GRID_SEARCH);
-#undef NB_SWEEP
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int k = 0; k < D; ++k) ai_sum[r][k] = F32 ? ai_sum[r][k] + (double)ai[r][k] : (double)ai[r][k];
-            }
-        }
-        // column contributions of the super-row to these source slots of tile J: the diagonal sweep leaves aj
-        // untouched (0), skipped waves hold 0; add the four waves in a fixed order and write ONE slab entry.
-        // After s_count rotations lane l holds the accumulators of particle (l + s_begin + s_count).
-        const int home = (lane + wk.s_begin + wk.s_count) & 63;
-#pragma unroll
-        for (int r = 0; r < RJ; ++r)
-#pragma unroll
-            for (int k = 0; k < D; ++k) s_aj[wave][r][k][home] = aj[r][k];
-        __syncthreads();
-        if (J > wk.tile_i) {                            // block-uniform: at least the first row lies below J
-            for (int idx = threadIdx.x; idx < RJ * D * 64; idx += NB_BLOCK) {
-                const int l = idx & 63, rk = idx >> 6;
-                const int r = rk / D, k = rk % D;
-                T v = s_aj[0][r][k][l];
-#pragma unroll
-                for (int w = 1; w < W; ++w) v += s_aj[w][r][k][l];
-                if (UNIFORM && HOOK == HOOK_GRID) v *= (T)gscale;    // the common mass (times 2^tm on the table-free path)
-                colslab[((size_t)wk.col_ord * D + k) * np + (size_t)J * B + (hs + r) * 64 + l] = v;
-            }
-        }
-        __syncthreads();
-      }
-    }
-
-    // row sums: one compact slot per (row, chunk)
-    const int slot = wk.slot + wave * wk.slot_stride;
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-            rowslab[((size_t)slot * D + k) * B + r * 64 + lane] =
-                (UNIFORM && HOOK == HOOK_GRID) ? ai_sum[r][k] * (double)gscale : ai_sum[r][k];
-}
 
 // Padding particles sit at `pad` in every coordinate (chosen by nb_launch_pack): r^2 stays finite and
 // y0^3 underflows to exactly 0 (fp64: r2 ~ 1e300, y0^3 ~ 1e-450; fp32: r2 ~ 1e36, y0^3 ~ 1e-54), so
@@ -820,41 +282,6 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
         for (int w = 1; w < NB_BLOCK / 64; ++w) t += s_red[w];
         part[blockIdx.x] = t;
     }
-}
-
-template <typename T, int D, int R, int HOOK, int LPC>
-hipError_t launch_sym_lpc(const T *packed, const SymWork *work, int nwork, double *rowslab, T *colslab, int np,
-                          int uniform, T eps2, const GridTables *tab, float gfac, hipStream_t st, NbKernelEvents ev,
-                          float mass_value)
-{
-    if (uniform && HOOK == HOOK_GRID) {
-        // uniform-mass grid kernel, valid only while the tables say so (GridTables::uniform_ok, known on the
-        // device only): launch it together with the general kernel, exactly one of the two does the work
-        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK, LPC>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
-                              nullptr, 0, packed, work, rowslab, colslab, np, eps2, tab, mass_value, 1);
-        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK, LPC>), dim3(nwork), dim3(NB_BLOCK), 0, st, nullptr,
-                              ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 2);
-    } else if (uniform)
-        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK, LPC>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
-                              ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 0);
-    else
-        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK, LPC>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
-                              ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 0);
-    return hipGetLastError();
-}
-
-template <typename T, int D, int R, int HOOK>
-hipError_t launch_sym_u(const T *packed, const SymWork *work, int nwork, double *rowslab, T *colslab, int np,
-                        int uniform, T eps2, const GridTables *tab, float gfac, hipStream_t st, NbKernelEvents ev,
-                        float mass_value = 0.0f, int levels = 0)
-{
-    if constexpr (HOOK == HOOK_GRID) {
-        if (levels > NB_LUT_MIN)
-            return launch_sym_lpc<T, D, R, HOOK, NB_MAX_LUT>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab,
-                                                             gfac, st, ev, mass_value);
-    }
-    return launch_sym_lpc<T, D, R, HOOK, NB_LUT_MIN>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab, gfac,
-                                                     st, ev, mass_value);
 }
 
 }  // namespace

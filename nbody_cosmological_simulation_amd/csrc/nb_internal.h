@@ -137,7 +137,14 @@ hipError_t nb_launch_force_f64(const double *pos, const double *mass, double *pa
                                hipStream_t st);
 hipError_t nb_launch_force_f32(const float *pos, const float *mass, double *partial, const ForceGeom &g,
                                int dim, int hook, int pa, float G, float eps2, const GridTables *tab, int levels,
-                               hipStream_t st);
+                               hipStream_t st, unsigned long long *bin_out = nullptr /* bin read-out, see below */);
+// Bin read-out (nb_quant_bin_sums): the production grid-mode pair loops instantiated with BINS = true add, for every
+// pair, the bin index they decided to per-particle integer checksums: bin_out = {s1[n], s2[n], {table-free pairs,
+// table pairs}} (unsigned 64-bit, zeroed by the caller).
+hipError_t nb_launch_force_sym_f32_bins(const float *packed, const SymWork *work, int nwork, double *rowslab,
+                                        float *colslab, int np, int dim, int r, int uniform, float eps2,
+                                        const GridTables *tab, float G, float mass_value, int levels,
+                                        unsigned long long *bin_out, int bin_n, hipStream_t st);
 // tensor-level _grid_quantize_safe of an fp32 tensor through threshold / value tables built for its own bounds
 // (bounds: device, {min, max} of the tensor as doubles; tab: device scratch); levels <= NB_MAX_LUT
 hipError_t nb_launch_grid_quantize_safe_tab(const float *in, float *out, int64_t count, int levels, float min_val,
@@ -258,7 +265,8 @@ hipError_t nb_launch_small_step(const void *pos_in, void *pos_out, void *vel, vo
                                 int do_kick /* 0 force only, 1 + closing kick, 2 + next opening kick + drift into pos_out */,
                                 int lanes /* 16 / 32 / 64 lanes per target */, hipStream_t st,
                                 const GridTables *tab = nullptr /* HOOK_GRID: this evaluation's tables */,
-                                double *part = nullptr /* INT8 / INT4: 2 n doubles, per-target min / max of the forces */);
+                                double *part = nullptr /* INT8 / INT4: 2 n doubles, per-target min / max of the forces */,
+                                unsigned long long *bin_out = nullptr /* HOOK_GRID: bin read-out (BINS instantiation) */);
 // second half of nb_launch_force_quant_step with caller-provided min / max partials (nblocks pairs of doubles)
 hipError_t nb_launch_force_quant_finish(float *acc, int64_t count, int levels, const double *partials, int nblocks,
                                         double *mn_mx, int16_t *bins, float *vel, float *pos, double half_dt, double dt,

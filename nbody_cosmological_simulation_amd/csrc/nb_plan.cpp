@@ -23,10 +23,6 @@ NbKnobs nb_read_knobs()
     if (k.sym_split != 1 && k.sym_split != 2 && k.sym_split != 4 && k.sym_split != 8) k.sym_split = 0;
     k.tail_pieces = env_int("NB_SYM_TAIL", 0);
     if (k.tail_pieces != 2 && k.tail_pieces != 4 && k.tail_pieces != 8 && k.tail_pieces != 16) k.tail_pieces = 0;
-    k.chunks = std::min(4, std::max(0, env_int("NB_CHUNKS", 0)));
-    k.chunk_graph = env_int("NB_CHUNK_GRAPH", 1) != 0;
-    k.chunk_serial = env_int("NB_CHUNK_SERIAL", 0) != 0;
-    k.chunk_prio = env_int("NB_CHUNK_PRIO", 0) != 0;
     k.r_onesided = env_int("NB_R", 0);
     k.no_prune = getenv("NB_NO_PRUNE") != nullptr;
     k.no_pe_sym = getenv("NB_NO_PE_SYM") != nullptr;
@@ -119,33 +115,6 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
     if (knobs.sym_cl > 0) cl = knobs.sym_cl;
     sp.cl = cl;
 
-    // ---- pipeline chunks (multi-GPU step): rank-independent super-row boundaries ----------------------
-    // Tiles below 4*B are complete once every owned super-row below B has been swept, so the reduction +
-    // all-reduce + kicks of that prefix can run while the remaining super-rows are still being computed.
-    // Only worth it when the remaining work outlasts a small all-reduce (tens of us over xGMI).
-    const double cyc_pair = (is_f64 ? 76.0 : 41.0) * (dim == 3 ? 19.0 / 14.0 : 1.0);
-    const double sweep_us = 64.0 * sp.r * sp.r * cyc_pair / 2200.0;                      // one wave, whole SIMD
-    const double force_us = ((double)T * (T + 1) / 2 / P) * sweep_us / (4.0 * in.cus);
-    // Default: ONE chunk.  Measured on MI355X / ROCm 7.2 (profiles/r02_chunk_pipeline_standin.txt): the cross-stream
-    // event hops a chunked step needs cost ~0.15-0.2 ms per step, more than the all-reduce latency they could hide at
-    // every size where that latency matters; NB_CHUNKS = 2..4 keeps the pipeline available (and tested).
-    int C = 1;
-    if (in.multi && knobs.chunks > 0) C = knobs.chunks;
-    if (SR < 2 * C) C = 1;
-    std::vector<int> bound(C + 1, 0);
-    bound[C] = SR;
-    if (C > 1) {
-        const double u = std::min(0.5, std::max(0.12, std::sqrt(80.0 / std::max(force_us, 1.0))));   // tile share of the last chunk
-        for (int c = 0; c + 1 < C; ++c) {
-            const double rem = std::pow(u, (double)(c + 1) / (C - 1));
-            int B = (int)std::floor(SR * (1.0 - rem));
-            if (B >= 2 * P) B -= B % (2 * P);                   // whole snake periods: equal shares per rank
-            bound[c + 1] = std::min(SR - (C - 1 - c), std::max(bound[c] + 1, B));
-        }
-    }
-    sp.chunk_tile.resize(C + 1);
-    for (int c = 0; c <= C; ++c) sp.chunk_tile[c] = 4 * bound[c];
-
     // ---- tail smoothing -------------------------------------------------------------------------------
     // Work items (4 rows x cl source tiles) all take the same time and the chip runs `slots` workgroups at
     // once (4 per CU at <= 128 VGPRs), so items beyond a multiple of `slots` cost a whole extra round on a
@@ -189,11 +158,7 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
     }
 
     // ---- work items, slots, slab entries ---------------------------------------------------------------
-    std::vector<int> chunk_of(SR, 0);
-    for (int c = 0; c < C; ++c)
-        for (int S = bound[c]; S < bound[c + 1]; ++S) chunk_of[S] = c;
-    struct Item { SymWork w; int chunk; };
-    std::vector<Item> items_v;
+    std::vector<SymWork> items_v;
     int slots = 0, ncol = 0;
     for (int S = 0; S < SR; ++S) {
         if (ord[S] < 0) continue;
@@ -205,7 +170,7 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
             for (int q = 0; q < nsp; ++q) {
                 SymWork wk{j0, j0 + ch * cl, std::min(T, j0 + (ch + 1) * cl), slots + ch * nsp + q, per_row,
                            ncol + q, q * (64 / nsp), 64 / nsp};
-                items_v.push_back({wk, chunk_of[S]});
+                items_v.push_back(wk);
             }
         slots += 4 * per_row;
         ncol += nsp;
@@ -219,15 +184,11 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
         for (int S = 0; S < SR; ++S) first[S + 1] = first[S] + (ord[S] >= 0 ? split_of[S] : 0);
         for (int J = 0; J < sp.tiles; ++J) sp.col_upto[J] = first[(J >> 2) + ((J & 3) ? 1 : 0)];
     }
-    // chunk by chunk; inside a chunk whole sweeps first, pieces last (longest processing time first)
-    std::stable_sort(items_v.begin(), items_v.end(), [](const Item &a, const Item &b) {
-        if (a.chunk != b.chunk) return a.chunk < b.chunk;
-        return (long long)(a.w.jt_end - a.w.jt_begin) * a.w.s_count > (long long)(b.w.jt_end - b.w.jt_begin) * b.w.s_count;
+    // whole sweeps first, pieces last (longest processing time first)
+    std::stable_sort(items_v.begin(), items_v.end(), [](const SymWork &a, const SymWork &b) {
+        return (long long)(a.jt_end - a.jt_begin) * a.s_count > (long long)(b.jt_end - b.jt_begin) * b.s_count;
     });
-    sp.work.reserve(items_v.size());
-    sp.chunk_work.assign(C + 1, 0);
-    for (const Item &it : items_v) { sp.work.push_back(it.w); sp.chunk_work[it.chunk + 1]++; }
-    for (int c = 0; c < C; ++c) sp.chunk_work[c + 1] += sp.chunk_work[c];
+    sp.work = std::move(items_v);
     sp.nslots = slots;
     sp.ncol = ncol;
     sp.col_bytes = (size_t)dim * sp.np * el * (size_t)std::max(ncol, 1);

@@ -1,9 +1,8 @@
 // nb_plan.h -- host-side planning of the pair-symmetric force evaluation (pure C++: no HIP call, no
-// allocation on a device), shared by nb_api.cpp and the device-less debug entry nb_plan_debug().
+// allocation on a device), shared by nb_api.cpp (build_sym_plan) and the device-less debug entry nb_plan_debug().
 //
 // What is planned: which (super-row, source-tile) work items THIS rank evaluates, where each item
-// leaves its row / column sums, in which order the reduction adds them, and how the items are grouped
-// into pipeline chunks of the multi-GPU step.  Everything here is a function of
+// leaves its row / column sums and in which order the reduction adds them.  Everything here is a function of
 // rank-independent quantities plus the rank itself, so every rank derives a consistent global plan
 // without talking to the others.
 #pragma once
@@ -18,9 +17,6 @@ struct NbKnobs {
     int sym_cl = 0;        // NB_SYM_CL: source tiles per work item; 0 = by work
     int sym_split = 0;     // NB_SYM_SPLIT: cut EVERY sweep into 1 / 2 / 4 / 8 pieces; 0 = tail smoothing only
     int tail_pieces = 0;   // NB_SYM_TAIL: pieces per sweep of the tail-smoothed super-rows (4 or 8); 0 = auto
-    int chunks = 0;        // NB_CHUNKS: pipeline chunks of the multi-GPU step (1..4); 0 = by work
-    bool chunk_serial = false, chunk_prio = false;   // experiments: NB_CHUNK_SERIAL (all force chunks on one stream), NB_CHUNK_PRIO (stream priorities)
-    bool chunk_graph = true;   // NB_CHUNK_GRAPH=0: enqueue the chunked steps eagerly instead of replaying a captured hipGraph
     int r_onesided = 0;    // NB_R: targets per thread of the one-sided fp64 kernel
     bool no_prune = false;   // NB_NO_PRUNE: all-pairs max-r2 scan at any N
     bool no_pe_sym = false;  // NB_NO_PE_SYM: one-sided potential-energy kernel
@@ -40,19 +36,15 @@ NbKnobs nb_read_knobs();
 struct SymPlanHost {
     bool enabled = false;
     int r = 2, tile_b = 128, tiles = 0, np = 0, nslots = 0, ncol = 0, cl = 1;
-    std::vector<SymWork> work;                       // sorted by (chunk, longest first)
+    std::vector<SymWork> work;                       // longest first
     std::vector<int> row_slot0, row_nslots, col_upto;   // per tile (see reduce_sym_kernel)
-    // pipeline chunks: chunk c = work[chunk_work[c] .. chunk_work[c+1]) = the owned super-rows in
-    // [chunk_tile[c]/4, chunk_tile[c+1]/4); once chunks 0..c are done the sums of tiles < chunk_tile[c+1]
-    // are complete on this rank.  chunk_tile is IDENTICAL on every rank (all-reduce prefixes must agree).
-    std::vector<int> chunk_work, chunk_tile;
     size_t col_bytes = 0, row_bytes = 0, packed_bytes = 0;
 };
 
 struct PlanInput {
     int n = 0, dim = 2, mode = 0, flags = 0, rank = 0, nranks = 1;
     bool is_f64 = true;
-    bool multi = false;      // a communicator will sum the partial forces (enables pipeline chunks)
+    bool multi = false;      // a communicator will sum the partial forces
     int cus = 256;           // compute units of the device
 };
 

@@ -46,11 +46,14 @@ template <> __device__ __forceinline__ double axpy_sep<double>(double a, double 
 template <> __device__ __forceinline__ float axpy_sep<float>(float a, float b, float s) { return __fadd_rn(a, __fmul_rn(b, s)); }
 
 // do_kick: 0 force only; 1 + closing half kick; 2 + next step's opening kick + drift (positions -> pos_out)
-template <typename T, int D, int HOOK, int S>
+// BINS (grid hook only): the same body with the quant-bin read-out -- per-target integer checksums s1 = sum_j k,
+// s2 = sum_j k ((j mod 65521) + 1) of the bin every pair was given, by whichever route the production code took
+// (table-free estimate / wave ballot / threshold fallback); bin_out = {s1[n], s2[n], {table-free pairs, table pairs}}.
+template <typename T, int D, int HOOK, int S, bool BINS = false>
 __global__ void __launch_bounds__(NB_BLOCK)
 small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__restrict__ vel, T *__restrict__ acc,
                   const T *__restrict__ mass, int n, T G, T eps2, T half_dt, T dt, int do_kick,
-                  const GridTables *__restrict__ tab, double *__restrict__ part)
+                  const GridTables *__restrict__ tab, double *__restrict__ part, unsigned long long *__restrict__ bin_out)
 {
     constexpr bool F64 = sizeof(T) == 8;
     constexpr int TG = NB_BLOCK / S;                 // targets per workgroup
@@ -84,6 +87,7 @@ small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__re
     double a[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) a[k] = 0.0;
+    long long b1 = 0, b2 = 0, bfast = 0, bexact = 0;     // BINS only
 
     for (int j0 = 0; j0 < n; j0 += SM_TILE) {
         __syncthreads();
@@ -119,9 +123,11 @@ small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__re
                 }
                 // (1 / q_k^1.5) * G of each pair's bin: table-free when no pair of the wave sits on a bin edge
                 // (DESIGN.md section 4.3), else floor(estimate) + one threshold compare, else binary search
+                int kb[U];                 // BINS: the bin each pair was given
+                bool kexact = true;
                 if (g_deg) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) w[u] = __fmul_rn(inv_r3_f(q[u] < 0.01f ? 0.01f : q[u]), G);
+                    for (int u = 0; u < U; ++u) { w[u] = __fmul_rn(inv_r3_f(q[u] < 0.01f ? 0.01f : q[u]), G); kb[u] = 0; }
                 } else if (g_fast) {
                     float kf[U], dev = 0.0f;
                     bool bad = false;
@@ -135,19 +141,42 @@ small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__re
                     }
                     if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
 #pragma unroll
-                        for (int u = 0; u < U; ++u)
-                            w[u] = s_lut[grid_bin_floor_estimate(s_thr, q[u], est_a, est_b, g_levels - 2)];
+                        for (int u = 0; u < U; ++u) {
+                            kb[u] = grid_bin_floor_estimate(s_thr, q[u], est_a, est_b, g_levels - 2);
+                            w[u] = s_lut[kb[u]];
+                        }
                     } else {
 #pragma unroll
-                        for (int u = 0; u < U; ++u)          // max(): softening^2 below the grid's floor
-                            w[u] = ldexpf(__builtin_amdgcn_exp2f(__builtin_fmaf(__builtin_fmaxf(kf[u], -kcf), c1, c0c)), g_tm);
+                        for (int u = 0; u < U; ++u) {        // max(): softening^2 below the grid's floor
+                            const float kc_ = __builtin_fmaxf(kf[u], -kcf);
+                            w[u] = ldexpf(__builtin_amdgcn_exp2f(__builtin_fmaf(kc_, c1, c0c)), g_tm);
+                            if constexpr (BINS) kb[u] = (int)__builtin_fminf(kc_ + kcf, 1e6f);
+                        }
+                        kexact = false;
                     }
                 } else if (g_est) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) w[u] = s_lut[grid_bin_floor_estimate(s_thr, q[u], est_a, est_b, g_levels - 2)];
+                    for (int u = 0; u < U; ++u) {
+                        kb[u] = grid_bin_floor_estimate(s_thr, q[u], est_a, est_b, g_levels - 2);
+                        w[u] = s_lut[kb[u]];
+                    }
                 } else {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) w[u] = s_lut[grid_bin_lookup(s_thr, q[u], NB_LUT_MIN)];
+                    for (int u = 0; u < U; ++u) {
+                        kb[u] = grid_bin_lookup(s_thr, q[u], NB_LUT_MIN);
+                        w[u] = s_lut[kb[u]];
+                    }
+                }
+                if constexpr (BINS) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int j = j0 + jj + u * S;
+                        if (j < n) {             // padding entries of the tile take part in no pair
+                            b1 += kb[u];
+                            b2 += (long long)kb[u] * (j % 65521 + 1);
+                            if (kexact) ++bexact; else ++bfast;
+                        }
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -190,6 +219,21 @@ small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__re
 #pragma unroll
         for (int k = 0; k < D; ++k) a[k] += __shfl_xor(a[k], off, 64);
     }
+    if constexpr (BINS) {
+#pragma unroll
+        for (int off = S / 2; off >= 1; off >>= 1) {
+            b1 += __shfl_xor(b1, off, 64);
+            b2 += __shfl_xor(b2, off, 64);
+            bfast += __shfl_xor(bfast, off, 64);
+            bexact += __shfl_xor(bexact, off, 64);
+        }
+        if (live && l == 0) {
+            bin_out[i] = (unsigned long long)b1;
+            bin_out[(size_t)n + i] = (unsigned long long)b2;
+            atomicAdd(&bin_out[2 * (size_t)n], (unsigned long long)bfast);
+            atomicAdd(&bin_out[2 * (size_t)n + 1], (unsigned long long)bexact);
+        }
+    }
     __shared__ double s_mm[NB_BLOCK / 16][2];        // INT8 / INT4: min / max of this workgroup's force components
     double lo = __builtin_inf(), hi = -__builtin_inf();
     if (live && l == 0) {
@@ -227,13 +271,14 @@ small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__re
     }
 }
 
-template <typename T, int D, int HOOK>
+template <typename T, int D, int HOOK, bool BINS = false>
 hipError_t launch_s(const T *pos_in, T *pos_out, T *vel, T *acc, const T *mass, int n, double G, double eps2, double half_dt,
-                    double dt, int do_kick, int lanes, hipStream_t st, const GridTables *tab = nullptr, double *part = nullptr)
+                    double dt, int do_kick, int lanes, hipStream_t st, const GridTables *tab = nullptr, double *part = nullptr,
+                    unsigned long long *bin_out = nullptr)
 {
 #define NB_SMALL(SS)                                                                                                       \
-    hipLaunchKernelGGL((small_step_kernel<T, D, HOOK, SS>), dim3((n + NB_BLOCK / SS - 1) / (NB_BLOCK / SS)), dim3(NB_BLOCK), 0, \
-                       st, pos_in, pos_out, vel, acc, mass, n, (T)G, (T)eps2, (T)half_dt, (T)dt, do_kick, tab, part)
+    hipLaunchKernelGGL((small_step_kernel<T, D, HOOK, SS, BINS>), dim3((n + NB_BLOCK / SS - 1) / (NB_BLOCK / SS)), dim3(NB_BLOCK), 0, \
+                       st, pos_in, pos_out, vel, acc, mass, n, (T)G, (T)eps2, (T)half_dt, (T)dt, do_kick, tab, part, bin_out)
     if (lanes == 64) NB_SMALL(64);
     else if (lanes == 32) NB_SMALL(32);
     else NB_SMALL(16);
@@ -255,12 +300,17 @@ int nb_small_lanes(int n)
 
 hipError_t nb_launch_small_step(const void *pos_in, void *pos_out, void *vel, void *acc, const void *mass, int n, int dim,
                                 int is_f64, int hook, double G, double eps2, double half_dt, double dt, int do_kick, int lanes,
-                                hipStream_t st, const GridTables *tab, double *part)
+                                hipStream_t st, const GridTables *tab, double *part, unsigned long long *bin_out)
 {
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
+    if (bin_out && hook != HOOK_GRID) return hipErrorInvalidValue;
     if (hook == HOOK_GRID) {
         if (is_f64 || !tab) return hipErrorInvalidValue;
         const float g32 = (float)G, e32 = (float)eps2;
+        if (bin_out) {          // bin read-out (nb_quant_bin_sums): the same kernel body, BINS = true
+            if (dim == 2) return launch_s<float, 2, HOOK_GRID, true>((const float *)pos_in, (float *)pos_out, (float *)vel, (float *)acc, (const float *)mass, n, g32, e32, half_dt, dt, do_kick, lanes, st, tab, part, bin_out);
+            return launch_s<float, 3, HOOK_GRID, true>((const float *)pos_in, (float *)pos_out, (float *)vel, (float *)acc, (const float *)mass, n, g32, e32, half_dt, dt, do_kick, lanes, st, tab, part, bin_out);
+        }
         if (dim == 2) return launch_s<float, 2, HOOK_GRID>((const float *)pos_in, (float *)pos_out, (float *)vel, (float *)acc, (const float *)mass, n, g32, e32, half_dt, dt, do_kick, lanes, st, tab, part);
         return launch_s<float, 3, HOOK_GRID>((const float *)pos_in, (float *)pos_out, (float *)vel, (float *)acc, (const float *)mass, n, g32, e32, half_dt, dt, do_kick, lanes, st, tab, part);
     }

@@ -82,10 +82,14 @@ def attach_communicator(handle):
         return
     uid = exchange_unique_id()
     N.check(L.nb_comm_init(handle, uid, len(uid)))
-    if os.environ.get("NB_NO_P2P") is None and os.environ.get("NB_P2P", "auto") != "0":
+    # The direct xGMI all-reduce is OPT-IN (NB_P2P=auto / force): it has only ever run between virtual ranks and
+    # between processes sharing one GPU's memory system -- until a run over real xGMI links is
+    # on record, RCCL carries every step by default.  auto: self-test + vote + timing comparison; force: no comparison.
+    p2p = os.environ.get("NB_P2P", "0")
+    if os.environ.get("NB_NO_P2P") is None and p2p in ("auto", "force", "1"):
         attach_direct_allreduce(_ctx["device"] if _ctx["device"] is not None else default_hip_device(),
                                 L.nb_comm_ready(), _ctx["rank"] if L.nb_comm_ready() > 1 else 0,
-                                compare_with_rccl=os.environ.get("NB_P2P", "auto") != "force")
+                                compare_with_rccl=p2p != "force")
 
 
 P2P_CAPACITY_BYTES = 4 << 20      # force vectors up to N*D = 524 288 doubles; longer ones are bandwidth-bound: RCCL

@@ -381,6 +381,22 @@ class GalaxySimulation:
         return dict(lmin=info[0], lmax=info[1], fmin=info[2], fmax=info[3], r2max=info[4], d2bins=d2, fbins=fb,
                     fast_path=bool(info[5]), fast_maxdev=info[6], fast_maxrel=info[7])
 
+    def quant_bin_sums(self, which: str = "last"):
+        """Quant-bin assignments read out of the PRODUCTION pair loop (include/nbody_amd.h nb_quant_bin_sums): per
+        particle p the exact integers sum_q k(p, q) and sum_q k(p, q) * ((q mod 65521) + 1) over its row of the N x N
+        bin matrix of quantization.py:119-121.  which: "last" (the path the last evaluation / step took), "tiled"
+        (what _compute_accelerations launches) or "small" (the one-launch small-system step kernel)."""
+        import numpy as np
+        self._flush(("positions", "masses"))
+        n = self.num_stars
+        s1, s2 = np.empty(n, np.int64), np.empty(n, np.int64)
+        info = (C.c_double * 8)()
+        N.check(N.lib().nb_quant_bin_sums(self._handle, {"last": 0, "tiled": 1, "small": 2}[which],
+                                          s1.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p), info))
+        return dict(sum_k=s1, sum_kw=s2, path={1: "sym", 2: "onesided", 3: "small"}[int(info[0])], shape=int(info[1]),
+                    uniform_kernel=bool(info[2]), fast_path=bool(info[3]), pairs_table_free=int(info[4]),
+                    pairs_table=int(info[5]), levels=int(info[6]))
+
     def quant_bins_rows(self, i0: int, i1: int):
         """Distance-bin indices of target rows [i0, i1) of the last force evaluation (grid modes), (i1-i0, N) int16."""
         import numpy as np

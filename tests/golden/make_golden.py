@@ -34,6 +34,8 @@ What is captured:
   G14 state hash: reproducibility.hash_tensor_state of the reference on golden states (fp32 / fp64 / fp16).
   G15 dtype combinations the stock class accepts beyond G1-G7: fp64 masses beside fp32 positions under every mode,
       grid modes (INT8 / INT4 / CUSTOM) on fp64 state, grid modes on float16 / bfloat16 state.
+  G20 quant-bin CHECKSUMS per target row (sum k, sum k * ((j mod 65521) + 1)) from the reference's bin matrices on the
+      stored g13 / g16 positions: what nb_quant_bin_sums reads out of the production pair loops.
   G7  half-typed state (float16 / bfloat16 tensors) through the cast modes and FLOAT64: energies before
       and after the promotion, state after three steps.
 
@@ -887,6 +889,64 @@ def g15():
     print("G15")
 
 
+def bin_checksums(k):
+    """Per-row integer checksums of a bin matrix k (rows = targets, columns = ALL N sources incl. the diagonal):
+    s1[i] = sum_j k[i, j],  s2[i] = sum_j k[i, j] * ((j mod 65521) + 1) -- what nb_quant_bin_sums reads out of the
+    production pair loops (include/nbody_amd.h)."""
+    k64 = np.asarray(k, np.int64)
+    w = (np.arange(k64.shape[1], dtype=np.int64) % 65521) + 1
+    return k64.sum(axis=1), (k64 * w[None, :]).sum(axis=1)
+
+
+def g20():
+    """Quant-bin checksums of the reference's own bin matrices, for the read-out of the production pair loops.
+    Inputs are the STORED positions of g13 (N = 4096 D = 2; N = 2048 D = 3 with the grid floor active) and g16
+    (N = 65 536, six target rows), so nothing depends on regenerating a galaxy on this host; the recomputed row CRCs
+    must equal the ones those fixtures hold.  g13 cases: every row, from the reference class's own
+    _grid_quantize_safe call (Spy); g16: the six rows through the reference's quantize_distance_squared on a row
+    block that contains the farthest pair (global bounds), as g16 itself does."""
+    import zlib
+    out = {}
+    for name in ("n4096_d2", "n2048_d3"):
+        g = np.load(os.path.join(OUT, f"g13_bins_{name}.npz"))
+        pos, vel, mass = (torch.from_numpy(g[k]).clone() for k in ("pos", "vel", "mass"))
+        n = pos.shape[0]
+        for mode in (PrecisionMode.INT8_SIM, PrecisionMode.INT4_SIM, PrecisionMode.CUSTOM):
+            with Spy() as spy:
+                ref_sim.GalaxySimulation(pos.clone(), vel.clone(), mass.clone(), precision_mode=mode, G=0.001,
+                                         softening=float(g["eps"]), dt=0.01)
+            tin, lv, mv, tout = spy.safe[0]
+            k, lmin, lmax = safe_bins(tin, lv, mv, tout)
+            tag = mode.value
+            k16 = np.ascontiguousarray(k.astype("<i2"))
+            crc = np.array([zlib.crc32(k16[i].tobytes()) for i in range(n)], np.uint32)
+            assert np.array_equal(crc, g[f"{tag}/row_crc"]), (name, tag, "bin matrix differs from the g13 fixture")
+            assert np.all(np.diag(k) == 0)
+            s1, s2 = bin_checksums(k)
+            out[f"g13_{name}/{tag}/s1"], out[f"g13_{name}/{tag}/s2"] = s1, s2
+            print("G20", name, tag, "sum k", int(s1.sum()))
+    g16_ = np.load(os.path.join(OUT, "g16_bins_n65536_rows.npz"))
+    pos = torch.from_numpy(g16_["pos"]).clone()
+    rows = [int(r) for r in g16_["rows"]]
+    eps2 = 0.1 ** 2
+    diff = pos.unsqueeze(0) - pos[rows].unsqueeze(1)
+    d2 = (diff ** 2).sum(dim=-1) + eps2
+    assert float(d2.max()) == float(g16_["r2max"])
+    for mode in (PrecisionMode.INT8_SIM, PrecisionMode.INT4_SIM, PrecisionMode.CUSTOM):
+        levels = GRID_LEVELS[mode]
+        q = ref_quant.quantize_distance_squared(d2.clone(), mode)
+        k, lmin, lmax = safe_bins(d2, levels, 0.01, q)
+        tag = mode.value
+        k16 = np.ascontiguousarray(k.astype("<i2"))
+        crc = np.array([zlib.crc32(k16[r].tobytes()) for r in range(len(rows))], np.uint32)
+        assert np.array_equal(crc, g16_[f"{tag}/row_crc"]), (tag, "bin rows differ from the g16 fixture")
+        s1, s2 = bin_checksums(k)
+        out[f"g16/{tag}/s1"], out[f"g16/{tag}/s2"] = s1, s2
+    out["g16/rows"] = np.array(rows, np.int64)
+    np.savez_compressed(os.path.join(OUT, "g20_bin_checksums.npz"), **out)
+    print("G20 done")
+
+
 def g14():
     """The reference's own state hash (reproducibility.py:227-232) on golden states."""
     import reproducibility as ref_repro
@@ -904,6 +964,6 @@ def g14():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
     for w in which:
         globals()[w]()

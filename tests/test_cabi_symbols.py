@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/nbody_amd.h but not exported"
     assert sorted(_native.EXPORTS) == declared
-    assert lib.nb_abi_version() == 2
+    assert lib.nb_abi_version() == 3
 
 
 def test_config_struct_layout_matches_header():

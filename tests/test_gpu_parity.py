@@ -449,13 +449,13 @@ def test_errors_are_exceptions(nb):
 
 def test_rccl_path_with_one_rank_communicator():
     """The multi-GPU step (nb_comm_init + RCCL all-reduce of forces / r2max / PE) exercised on one
-    GPU with a 1-rank communicator: results must be bit-identical to the comm-less path -- also when the
-    step runs as 2 / 3 / 4 pipelined chunks (prefix reductions + sliced all-reduce on the collective stream,
-    double-buffered packed positions), and all simulations of the process share ONE communicator."""
+    GPU with a 1-rank communicator: results must be bit-identical to the comm-less path, on the RCCL carrier and on
+    the (opt-in) direct all-reduce; all simulations of the process share ONE communicator; a handle that outlives
+    nb_comm_shutdown fails with NB_ERR_COMM instead of touching the destroyed communicator."""
     import subprocess
     import sys
     script = r'''
-import os, sys
+import ctypes, os, sys
 sys.path.insert(0, os.environ["NB_ROOT"])
 import numpy as np, torch
 import nbody_cosmological_simulation_amd as nb
@@ -474,23 +474,23 @@ os.environ["NBODY_FORCE_COMM"] = "1"
 os.environ["NB_P2P"] = "force"          # with one rank RCCL's all-reduce is a no-op and would win the timing comparison
 runtime.init_distributed(device=0)
 assert _native.lib().nb_comm_ready() == 0
-for chunks in ("1", "1-rccl", "2", "3", "4"):
-    os.environ["NB_CHUNKS"] = chunks[0]
-    if chunks == "1-rccl":
+for carrier in ("direct", "rccl"):
+    if carrier == "rccl":
         os.environ["NB_NO_P2P"] = "1"                  # read when a simulation is created: force vectors through RCCL
     for m, (p0, v0, e0) in base.items():
         p1, v1, e1 = run(m)
-        assert np.array_equal(p0, p1), (m, chunks)
-        assert np.array_equal(v0, v1), (m, chunks)
-        assert e0 == e1, (m, chunks)
+        assert np.array_equal(p0, p1), (m, carrier)
+        assert np.array_equal(v0, v1), (m, carrier)
+        assert e0 == e1, (m, carrier)
     os.environ.pop("NB_NO_P2P", None)
     assert _native.lib().nb_comm_ready() == 1          # one communicator for all of them
-    # ... and beside it the direct all-reduce (1 rank: its kernel just moves the vector), which the unchunked
-    # step uses by default
+    # ... and beside it the direct all-reduce (1 rank: its kernel just moves the vector), opted into with NB_P2P
     assert _native.lib().nb_comm_p2p_state() == 2, runtime._p2p_log
     assert runtime.allreduce_label().startswith("direct")
+info = (ctypes.c_int32 * 8)()
+assert _native.lib().nb_comm_info(info) == 0
+assert (info[0], info[1], info[3], info[4], info[5]) == (1, 0, 0, 1, 2), list(info)     # 1 rank, RCCL count 1, direct enabled
 # two simulations alive at once share the ONE input buffer of the direct path: interleaved steps stay bit-identical
-os.environ["NB_CHUNKS"] = "1"
 a = nb.GalaxySimulation(pos, vel, mass, precision_mode=nb.PrecisionMode.FLOAT64)
 b = nb.GalaxySimulation(pos, vel, mass, precision_mode=nb.PrecisionMode.FLOAT32)
 for k in (3, 2):
@@ -498,9 +498,21 @@ for k in (3, 2):
 for sim, m in ((a, nb.PrecisionMode.FLOAT64), (b, nb.PrecisionMode.FLOAT32)):
     assert np.array_equal(sim.positions.numpy(), base[m][0]), m
     assert np.array_equal(sim.velocities.numpy(), base[m][1]), m
-a.close(); b.close()
+a.close()
 runtime.shutdown()
 assert _native.lib().nb_comm_ready() == 0 and _native.lib().nb_comm_p2p_state() == 0
+# b outlived the communicator it borrowed: every further collective use must fail cleanly (ADVICE r2)
+try:
+    b.run(1)
+    raise SystemExit("a step on a handle whose communicator was shut down did not fail")
+except _native.NativeError as e:
+    assert e.code == -6 and "shut down" in str(e), e
+try:
+    b.get_potential_energy()
+    raise SystemExit("an energy evaluation on a handle whose communicator was shut down did not fail")
+except _native.NativeError as e:
+    assert e.code == -6, e
+b.close()
 print("RCCL-1RANK-OK")
 '''
     env = dict(os.environ, NB_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -1077,6 +1089,15 @@ def test_grid_force_kernel_decides_pairs_at_the_bin_edges(nb, monkeypatch, level
     got = sim.quant_debug(bins=True)
     assert np.float32(got["lmax"]) == np.float32(dbg["lmax"])
     assert np.array_equal(got["d2bins"], dbg["d2bins"])
+    # ... and the force kernel's OWN decisions, read out of its pair loop (round 3): every star's bin checksums
+    bs = sim.quant_bin_sums("tiled")
+    k64 = dbg["d2bins"].astype(np.int64)
+    wgt = (np.arange(n, dtype=np.int64) % 65521) + 1
+    assert bs["path"] == "sym" and bs["shape"] == r
+    assert np.array_equal(bs["sum_k"], k64.sum(axis=1)), "the pair loop put a pair into a bin the reference formula does not"
+    assert np.array_equal(bs["sum_kw"], (k64 * wgt[None, :]).sum(axis=1))
+    if levels <= 256:
+        assert bs["fast_path"] and bs["pairs_table"] > 0 and bs["pairs_table_free"] > 0     # both routes were taken
     acc = sim.accelerations.numpy().astype(np.float64)
     assert abs(acc[0, 0] - ref[0, 0]) <= 2e-6 * abs(ref[0, 0]), (acc[0], ref[0])
     assert np.abs(acc - ref).max() <= 2e-6 * np.abs(ref).max()

@@ -451,6 +451,23 @@ def test_g13_bins_at_scale_vs_reference(fname, mode):
         assert relerr(acc, g[f"{mode}/acc0"]) < 2e-6
 
 
+@pytest.mark.parametrize("fname", G13)
+@pytest.mark.parametrize("mode", ["int8_sim", "int4_sim", "custom"])
+def test_g20_bin_checksums_vs_reference(fname, mode):
+    """The per-row integer checksums the HIP path's production pair loops report (nb_quant_bin_sums: sum_j k and
+    sum_j k * ((j mod 65521) + 1)) computed from the ORACLE's bin matrix equal the ones make_golden.py g20 computed
+    from the reference's bin matrix -- so the fixture and the checksum definition are pinned on the CPU too."""
+    g = load_golden(fname)
+    ref = load_golden("g20_bin_checksums.npz")
+    case = fname[len("g13_bins_"):-len(".npz")]
+    _, dbg = O.accelerations(g["pos"], g["mass"], mode, softening=float(g["eps"]), debug=True)
+    k = dbg["d2bins"].astype(np.int64)
+    assert np.all(np.diag(k) == 0)
+    w = (np.arange(k.shape[1], dtype=np.int64) % 65521) + 1
+    assert np.array_equal(k.sum(axis=1), ref[f"g13_{case}/{mode}/s1"])
+    assert np.array_equal((k * w[None, :]).sum(axis=1), ref[f"g13_{case}/{mode}/s2"])
+
+
 def test_g14_state_hash_matches_reference():
     """checkpoint.state_hash against hashes produced by the reference's reproducibility.hash_tensor_state."""
     import json
