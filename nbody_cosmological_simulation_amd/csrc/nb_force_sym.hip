@@ -36,10 +36,12 @@ template <> __device__ __forceinline__ float axpy_rn<float>(float a, float b, fl
 // along: v += a*(dt/2); x += v*dt (simulation.py:132,135, separate mul/add roundings like torch).
 // KICK = 2 additionally applies the closing half kick of the PREVIOUS step first (simulation.py:141),
 // which the multi-GPU / force-quantising paths cannot fuse into their reduction.
+// spread != 0 (potential energy with uniform masses, where no mass factor silences the padding): padding particle
+// number k sits at pad * (1 + k) along x, so pad-pad pairs are as far apart as pad-real ones.
 template <typename T, int D, int KICK>
 __global__ void __launch_bounds__(NB_BLOCK)
 pack_kernel(T *__restrict__ pos, T *__restrict__ vel, const T *__restrict__ acc, const T *__restrict__ mass,
-            T *__restrict__ packed, int n, int np, T half_dt, T dt, T gfac, T pad, int p_begin, int p_end)
+            T *__restrict__ packed, int n, int np, T half_dt, T dt, T gfac, T pad, int p_begin, int p_end, int spread)
 {
     const int p = p_begin + blockIdx.x * NB_BLOCK + threadIdx.x;
     if (p >= p_end) return;
@@ -61,7 +63,7 @@ pack_kernel(T *__restrict__ pos, T *__restrict__ vel, const T *__restrict__ acc,
         packed[(size_t)D * np + p] = gfac * mass[p];
     } else {
 #pragma unroll
-        for (int k = 0; k < D; ++k) packed[(size_t)k * np + p] = pad;
+        for (int k = 0; k < D; ++k) packed[(size_t)k * np + p] = (spread && k == 0) ? pad * (T)(1 + (p - n)) : pad;
         packed[(size_t)D * np + p] = (T)0;
     }
 }
@@ -179,10 +181,112 @@ finish_sums64_kernel(const double *__restrict__ sums64, double scale, float *__r
 // Potential energy over the same tile-pair work list: sum over unordered pairs of
 // m_a m_b / sqrt(r2 + eps2) (simulation.py:176-192; the caller applies -G).  Off-diagonal tile
 // pairs hold every unordered pair once; a diagonal tile holds each twice plus the self pairs, so
-// those terms carry weight 1/2 and the self pairs are skipped.  F32T: term arithmetic in fp32 with
-// correctly rounded sqrt / divide (fp32-typed state); otherwise fp64 with v_rsq_f64 + a third-order
-// step.  Per-lane fp64 sums, wave shuffle + LDS block sum, one partial per workgroup.
-template <typename T, int D, int R, bool F32T>
+// those terms carry weight 1/2 and the self pairs are skipped.
+//   UNIFORM   all masses equal: the mass product is a constant the host applies to the finished sum -- no mass
+//             loads, rotations or multiplies in the pair loop (padding particles are spread out by pack_kernel so
+//             that pad-pad pairs are as far apart as pad-real ones: 1 / dist ~ 1e-150, absorbed).
+//   F32T      fp32-typed state: term arithmetic in fp32 (one v_rsq_f32 per pair; r2 from fused multiply-adds -- no
+//             rounding DECISION hangs on it here, unlike the grid modes), source slots paired in float2 halves so the
+//             differences, r2 and the accumulation issue as v_pk_*_f32; fp32 running sums of one tile (R/2 x 2 chains
+//             of 64 R terms) are folded into the fp64 sum after every tile.
+//   otherwise fp64: v_rsq_f64 (2^-24) + ONE Newton step folded into the accumulation, y = y0 (1 + e / 2), e = 1 - q y0^2:
+//             the neglected 3 e^2 / 8 is < 5e-15 relative (asserted energy bar: 1e-12).  8 VALU + 1 rsq per pair for
+//             uniform masses in 2-D (the force kernel: 14 + 1).
+// Per-lane fp64 sums, wave shuffle + LDS block sum, one partial per workgroup.
+// TM: type the masses are carried (and rotated) in -- float when the masses are fp32- / half-typed (their product is
+// rounded in that dtype upstream: one fp32 multiply and one conversion per pair instead of three conversions), else T.
+template <typename T, typename TM, int D, int R, bool DIAG, bool UNIFORM>
+__device__ __forceinline__ double pe_sweep_f64(const T (&xi)[R][D], const TM (&mi)[R], T (&xj)[R][D], TM (&mj)[R], double eps2,
+                                               int mass_dt, int rot_addr, int s_begin, int s_count)
+{
+    double tsum[R];             // independent chains: a single accumulator would serialise the adds
+#pragma unroll
+    for (int r = 0; r < R; ++r) tsum[r] = 0.0;
+    double half = 0.5, one = 1.0;
+    asm volatile("" : "+v"(half), "+s"(one));
+#pragma unroll 1
+    for (int s = s_begin; s < s_begin + s_count; ++s) {
+#pragma unroll
+        for (int rj = 0; rj < R; ++rj) {
+#pragma unroll
+            for (int ri = 0; ri < R; ++ri) {
+                double d[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) d[k] = (double)xj[rj][k] - (double)xi[ri][k];
+                double q = __builtin_fma(d[D - 1], d[D - 1], eps2);
+#pragma unroll
+                for (int k = D - 2; k >= 0; --k) q = __builtin_fma(d[k], d[k], q);
+                const double y0 = __builtin_amdgcn_rsq(q);
+                const double e = __builtin_fma(-(q * y0), y0, one);
+                const double c = __builtin_fma(e, half, one);
+                if (UNIFORM) {
+                    if (DIAG && ri == rj) tsum[rj] = (s == 0) ? tsum[rj] : __builtin_fma(y0, c, tsum[rj]);     // self pair
+                    else tsum[rj] = __builtin_fma(y0, c, tsum[rj]);
+                } else {
+                    double mp;
+                    if constexpr (std::is_same_v<TM, float>) mp = (double)mass_prod_f32(mi[ri], mj[rj], mass_dt);
+                    else mp = (double)mi[ri] * (double)mj[rj];
+                    const double term = mp * (y0 * c);
+                    if (DIAG && ri == rj) tsum[rj] += (s == 0) ? 0.0 : term;
+                    else tsum[rj] += term;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) xj[rj][k] = rot1<T>(xj[rj][k], rot_addr);
+            if (!UNIFORM) mj[rj] = rot1<TM>(mj[rj], rot_addr);
+        }
+    }
+    double tile = tsum[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) tile += tsum[r];
+    return DIAG ? 0.5 * tile : tile;
+}
+
+template <int D, int R, bool DIAG, bool UNIFORM>
+__device__ __forceinline__ double pe_sweep_f32(const float (&xi)[R][D], const float (&mi)[R], f2 (&xj2)[R / 2][D], f2 (&mj2)[R / 2],
+                                               float eps2, int mass_dt, int rot_addr, int s_begin, int s_count)
+{
+    f2 ts2[R / 2];
+#pragma unroll
+    for (int h = 0; h < R / 2; ++h) ts2[h] = f2{0.0f, 0.0f};
+#pragma unroll 1
+    for (int s = s_begin; s < s_begin + s_count; ++s) {
+#pragma unroll
+        for (int h = 0; h < R / 2; ++h) {
+#pragma unroll
+            for (int ri = 0; ri < R; ++ri) {
+                f2 d[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) d[k] = xj2[h][k] - xi[ri][k];
+                f2 r2 = __builtin_elementwise_fma(d[D - 1], d[D - 1], f2{eps2, eps2});
+#pragma unroll
+                for (int k = D - 2; k >= 0; --k) r2 = __builtin_elementwise_fma(d[k], d[k], r2);
+                f2 y = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+                if (DIAG && s == 0) {                       // self pairs: slot 2h / 2h + 1 against target slot ri
+                    if (2 * h == ri) y.x = 0.0f;
+                    if (2 * h + 1 == ri) y.y = 0.0f;
+                }
+                if (UNIFORM) {
+                    ts2[h] = ts2[h] + y;
+                } else {
+                    f2 mp = mj2[h] * mi[ri];                 // exact for half inputs; rounded to the masses' dtype like upstream
+                    if (mass_dt == NB_F16) mp = f2{round_f16(mp.x), round_f16(mp.y)};
+                    else if (mass_dt == NB_BF16) mp = f2{round_bf16(mp.x), round_bf16(mp.y)};
+                    ts2[h] = __builtin_elementwise_fma(mp, y, ts2[h]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) xj2[h][k] = rot1_f2(xj2[h][k], rot_addr);
+            if (!UNIFORM) mj2[h] = rot1_f2(mj2[h], rot_addr);
+        }
+    }
+    double tile = 0.0;
+#pragma unroll
+    for (int h = 0; h < R / 2; ++h) tile += (double)ts2[h].x + (double)ts2[h].y;
+    return DIAG ? 0.5 * tile : tile;
+}
+
+template <typename T, int D, int R, bool F32T, bool UNIFORM>
 __global__ void __launch_bounds__(NB_BLOCK)
 potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work, double *__restrict__ part,
                      int np, double eps2, float eps2_f, int mass_dt)
@@ -193,84 +297,50 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int I = wk.tile_i + wave;
     const int rot_addr = ((lane + 1) & 63) << 2;
+    using TA = std::conditional_t<F32T, float, T>;      // arithmetic type of the pair terms
 
-    T xi[R][D], mi[R];
+    TA xi[R][D], mi[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int p = I * B + r * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < D; ++k) xi[r][k] = packed[(size_t)k * np + p];
-        mi[r] = packed[(size_t)D * np + p];
+        for (int k = 0; k < D; ++k) xi[r][k] = (TA)packed[(size_t)k * np + p];
+        mi[r] = UNIFORM ? (TA)1 : (TA)packed[(size_t)D * np + p];
     }
     double sum = 0.0;
     for (int J = max(wk.jt_begin, I); J < wk.jt_end; ++J) {
-        T xj[R][D], mj[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int p = J * B + r * 64 + ((lane + wk.s_begin) & 63);
-#pragma unroll
-            for (int k = 0; k < D; ++k) xj[r][k] = packed[(size_t)k * np + p];
-            mj[r] = packed[(size_t)D * np + p];
-        }
         const bool diag = (J == I);
-        double tsum[R];             // independent chains: a single accumulator would serialise the adds
+        if constexpr (F32T) {
+            f2 xj2[R / 2][D], mj2[R / 2];
 #pragma unroll
-        for (int r = 0; r < R; ++r) tsum[r] = 0.0;
-#pragma unroll 1
-        for (int s = wk.s_begin; s < wk.s_begin + wk.s_count; ++s) {
+            for (int h = 0; h < R / 2; ++h) {
+                const int p0 = J * B + 2 * h * 64 + ((lane + wk.s_begin) & 63);
 #pragma unroll
-            for (int ri = 0; ri < R; ++ri) {
-#pragma unroll
-                for (int rj = 0; rj < R; ++rj) {
-                    double term;
-                    if (F32T) {
-                        float d2 = 0.0f;
-#pragma unroll
-                        for (int k = 0; k < D; ++k) {
-                            const float df = __fsub_rn((float)xj[rj][k], (float)xi[ri][k]);
-                            const float sq = __fmul_rn(df, df);
-                            d2 = (k == 0) ? sq : __fadd_rn(d2, sq);
-                        }
-#ifdef NB_PE_F32_EXACT
-                        const float dist = __builtin_sqrtf(__fadd_rn(d2, eps2_f));
-                        term = (double)__fdiv_rn(mass_prod_f32((float)mi[ri], (float)mj[rj], mass_dt), dist);
-#else
-                        // m_a m_b / sqrt(q) as one v_rsq_f32 and a product (1.5 ulp per term, unbiased) instead of the
-                        // correctly rounded sqrt and divide (about 25 instructions): the terms are summed in fp64 here,
-                        // while the reference's own fp32 .sum() of N^2 terms carries ~1e-7 of rounding -- the last ulp
-                        // of a term is far below what the result can show (measured: DESIGN.md 4.6)
-                        const float y = __builtin_amdgcn_rsqf(__fadd_rn(d2, eps2_f));
-                        term = (double)__fmul_rn(mass_prod_f32((float)mi[ri], (float)mj[rj], mass_dt), y);
-#endif
-                    } else {
-                        double q = eps2;
-#pragma unroll
-                        for (int k = 0; k < D; ++k) {
-                            const double df = (double)xj[rj][k] - (double)xi[ri][k];
-                            q = __builtin_fma(df, df, q);
-                        }
-                        const double y0 = __builtin_amdgcn_rsq(q);
-                        const double e = __builtin_fma(-q * y0, y0, 1.0);
-                        const double y = __builtin_fma(y0 * e, __builtin_fma(e, 0.375, 0.5), y0);
-                        const double mp = mass_dt != NB_F64 ? (double)mass_prod_f32((float)mi[ri], (float)mj[rj], mass_dt)
-                                                            : (double)mi[ri] * (double)mj[rj];
-                        term = mp * y;
-                    }
-                    if (ri == rj) term = (diag && s == 0) ? 0.0 : term;     // self pair
-                    tsum[rj] += term;
-                }
+                for (int k = 0; k < D; ++k) xj2[h][k] = f2{(float)packed[(size_t)k * np + p0], (float)packed[(size_t)k * np + p0 + 64]};
+                mj2[h] = UNIFORM ? f2{1.0f, 1.0f} : f2{(float)packed[(size_t)D * np + p0], (float)packed[(size_t)D * np + p0 + 64]};
             }
+            sum += diag ? pe_sweep_f32<D, R, true, UNIFORM>(xi, mi, xj2, mj2, eps2_f, mass_dt, rot_addr, wk.s_begin, wk.s_count)
+                        : pe_sweep_f32<D, R, false, UNIFORM>(xi, mi, xj2, mj2, eps2_f, mass_dt, rot_addr, wk.s_begin, wk.s_count);
+        } else {
+            T xj[R][D], mj[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
+                const int p = J * B + r * 64 + ((lane + wk.s_begin) & 63);
 #pragma unroll
-                for (int k = 0; k < D; ++k) xj[r][k] = rot1<T>(xj[r][k], rot_addr);
-                mj[r] = rot1<T>(mj[r], rot_addr);
+                for (int k = 0; k < D; ++k) xj[r][k] = packed[(size_t)k * np + p];
+                mj[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
+            }
+            if (!UNIFORM && mass_dt != NB_F64) {            // kernel-uniform: masses typed narrower than the positions
+                float mif[R], mjf[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { mif[r] = (float)mi[r]; mjf[r] = (float)mj[r]; }
+                sum += diag ? pe_sweep_f64<T, float, D, R, true, UNIFORM>(xi, mif, xj, mjf, eps2, mass_dt, rot_addr, wk.s_begin, wk.s_count)
+                            : pe_sweep_f64<T, float, D, R, false, UNIFORM>(xi, mif, xj, mjf, eps2, mass_dt, rot_addr, wk.s_begin, wk.s_count);
+            } else {
+                sum += diag ? pe_sweep_f64<T, T, D, R, true, UNIFORM>(xi, mi, xj, mj, eps2, mass_dt, rot_addr, wk.s_begin, wk.s_count)
+                            : pe_sweep_f64<T, T, D, R, false, UNIFORM>(xi, mi, xj, mj, eps2, mass_dt, rot_addr, wk.s_begin, wk.s_count);
             }
         }
-        double tile = tsum[0];
-#pragma unroll
-        for (int r = 1; r < R; ++r) tile += tsum[r];
-        sum += diag ? 0.5 * tile : tile;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
@@ -288,7 +358,7 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
 
 hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mass, void *packed, int n, int np,
                           int dim, int is_f64, int kick, double half_dt, double dt, double gfac, int f32_pairs,
-                          hipStream_t st, int p_begin, int p_end)
+                          hipStream_t st, int p_begin, int p_end, int spread_pad)
 {
     if (p_end < 0) p_end = np;
     if (p_end <= p_begin) return hipSuccess;
@@ -299,7 +369,7 @@ hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mas
 #define NB_PACK(TT, DD, KK) \
     hipLaunchKernelGGL((pack_kernel<TT, DD, KK>), dim3(grid), dim3(NB_BLOCK), 0, st, (TT *)pos, (TT *)vel, \
                        (const TT *)acc, (const TT *)mass, (TT *)packed, n, np, (TT)half_dt, (TT)dt, (TT)gfac, (TT)pad, \
-                       p_begin, p_end)
+                       p_begin, p_end, spread_pad)
 #define NB_PACK_K(TT, DD) do { if (kick == 2) NB_PACK(TT, DD, 2); else if (kick == 1) NB_PACK(TT, DD, 1); else NB_PACK(TT, DD, 0); } while (0)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64) { if (dim == 2) NB_PACK_K(double, 2); else NB_PACK_K(double, 3); }
@@ -352,12 +422,18 @@ hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int
 }
 
 hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int nwork, double *part, int np, int dim,
-                                   int r, int is_f64, int f32_terms, int mass_dt, double eps2, hipStream_t st)
+                                   int r, int is_f64, int f32_terms, int mass_dt, double eps2, int uniform, hipStream_t st)
 {
     const float e32 = (float)eps2;
-#define NB_PES(TT, DD, RR, FF) \
-    hipLaunchKernelGGL((potential_sym_kernel<TT, DD, RR, FF>), dim3(nwork), dim3(NB_BLOCK), 0, st, (const TT *)packed, \
-                       work, part, np, eps2, e32, mass_dt)
+#define NB_PES(TT, DD, RR, FF)                                                                                           \
+    do {                                                                                                                 \
+        if (uniform)                                                                                                     \
+            hipLaunchKernelGGL((potential_sym_kernel<TT, DD, RR, FF, true>), dim3(nwork), dim3(NB_BLOCK), 0, st,         \
+                               (const TT *)packed, work, part, np, eps2, e32, mass_dt);                                  \
+        else                                                                                                             \
+            hipLaunchKernelGGL((potential_sym_kernel<TT, DD, RR, FF, false>), dim3(nwork), dim3(NB_BLOCK), 0, st,        \
+                               (const TT *)packed, work, part, np, eps2, e32, mass_dt);                                  \
+    } while (0)
     if (is_f64) {
         if (dim == 2 && r == 4) { if (f32_terms) NB_PES(double, 2, 4, true); else NB_PES(double, 2, 4, false); }
         else if (dim == 2 && r == 2) { if (f32_terms) NB_PES(double, 2, 2, true); else NB_PES(double, 2, 2, false); }

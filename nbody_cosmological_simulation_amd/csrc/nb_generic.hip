@@ -139,7 +139,12 @@ generic_force_kernel(const S *__restrict__ pos, const S *__restrict__ mass, doub
     const int A = (W2 == NB_F64 || P == NB_F64) ? NB_F64 : NB_F32;
     const double eps2_P = rnd(P, g.eps2_py);
     const double min_P = rnd(P, 0.01);
-    const double Gs = rnd(Q, g.G);
+    // A Python scalar that MULTIPLIES / DIVIDES a half tensor stays in float (torch's CPU mul / div kernels take the
+    // scalar operand in opmath precision; one that is ADDED is rounded to the tensor's dtype first -- measured on
+    // torch 2.10, tests/test_oracle_golden.py::test_torch_scalar_semantics_on_half_tensors).  Round 2 rounded G and
+    // (levels - 1) to the half type here: G = 0.001 became 0.0010004 in float16, a 4e-4 error of every force, which
+    // showed up as 4 % of the INT8 force values in a neighbouring force bin.
+    const double Gs = rnd(opmath(Q), g.G);
     const int L = g.levels;
     double lmin = 0.0, lmax = 0.0, range = 0.0, lm1 = 0.0;
     bool degenerate = false;
@@ -148,7 +153,7 @@ generic_force_kernel(const S *__restrict__ pos, const S *__restrict__ mass, doub
         lmin = gqs_log(P, eps2_P, min_P);         // the diagonal (r2 = eps2) is part of the N x N tensor
         lmax = gqs_log(P, r2max, min_P);
         range = rnd(P, lmax - lmin);
-        lm1 = rnd(P, (double)(L - 1));
+        lm1 = rnd(opmath(P), (double)(L - 1));    // scalar of `* (levels - 1)` / `/ (levels - 1)`: opmath, see Gs
         degenerate = range < 1e-10;               // NaN compares false: quantised values become NaN like upstream
     }
     double xi[D], acc[D];

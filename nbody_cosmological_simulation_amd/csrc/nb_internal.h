@@ -102,7 +102,8 @@ struct NbKernelEvents {
 // kick + drift of a step (simulation.py:132,135)
 hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mass, void *packed, int n, int np,
                           int dim, int is_f64, int kick, double half_dt, double dt, double gfac, int f32_pairs,
-                          hipStream_t st, int p_begin = 0, int p_end = -1 /* packed entries [p_begin, p_end); -1 = np */);
+                          hipStream_t st, int p_begin = 0, int p_end = -1 /* packed entries [p_begin, p_end); -1 = np */,
+                          int spread_pad = 0 /* padding particles at distinct far positions (uniform-mass potential energy) */);
 hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, int nwork, double *rowslab,
                                    double *colslab, int np, int dim, int r, int uniform, int pa_f32, double eps2,
                                    hipStream_t st, NbKernelEvents ev = {});
@@ -111,7 +112,8 @@ hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int
                                    const GridTables *tab, float G, float mass_value, int levels, hipStream_t st,
                                    NbKernelEvents ev = {});
 hipError_t nb_launch_potential_sym(const void *packed, const SymWork *work, int nwork, double *part, int np, int dim,
-                                   int r, int is_f64, int f32_terms, int mass_dt /* nb_dtype of the masses */, double eps2, hipStream_t st);
+                                   int r, int is_f64, int f32_terms, int mass_dt /* nb_dtype of the masses */, double eps2,
+                                   int uniform /* all masses equal: the caller applies the mass product to the sum */, hipStream_t st);
 hipError_t nb_launch_final_sum(const double *part, int count, double *out, hipStream_t st);
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
                                 const int *row_nslots, const int *col_upto, int tile_b, int n,

@@ -508,6 +508,7 @@ int energy_eval(nb_sim *s, double *kinetic, double *potential)
 {
     const nb_config &c = s->cfg;
     double host[2] = {0, 0};
+    bool pe_uniform = false;
     const int hp_v = is_half(s->logical[1]) ? s->logical[1] : -1;   // NB_F16 == 0: "none" is -1
     const int hp_x = is_half(s->logical[0]) ? s->logical[0] : -1;
     if (kinetic) {
@@ -522,10 +523,14 @@ int energy_eval(nb_sim *s, double *kinetic, double *potential)
                             !s->knobs.no_pe_sym;
         if (pe_sym) {
             // same tile-pair work list as the force kernel; `packed` is scratch between force evaluations
+            // uniform masses: no mass factor in the pair loop; m * m (rounded like upstream's masses[i] * masses[j], in the
+            // masses' dtype) multiplies the finished sum below
+            pe_uniform = s->mass_uniform;
             HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, s->is_f64, 0, 0.0, 0.0,
-                                  1.0, s->is_f64 && s->logical[0] != NB_F64, s->stream));
+                                  1.0, s->is_f64 && s->logical[0] != NB_F64, s->stream, 0, -1, pe_uniform ? 1 : 0));
             HIPCHK(nb_launch_potential_sym(sp.packed, sp.work, sp.nwork, s->scratch, sp.np, c.dim, sp.r, s->is_f64,
-                                           s->logical[0] != NB_F64, s->logical[2], c.softening_sq, s->stream));
+                                           s->logical[0] != NB_F64, s->logical[2], c.softening_sq, pe_uniform ? 1 : 0,
+                                           s->stream));
             HIPCHK(nb_launch_final_sum(s->scratch, sp.nwork, s->scalars + 3, s->stream));
         } else {
             HIPCHK(nb_launch_potential(s->pos, s->mass, s->geom, c.dim, s->is_f64, s->logical[0] != NB_F64,
@@ -548,7 +553,10 @@ int energy_eval(nb_sim *s, double *kinetic, double *potential)
     }
     if (potential) {
         const int t = promote(s->logical[0], s->logical[2]);
-        *potential = round_dt(t, round_dt(t, -c.G) * round_dt(t, host[1]));
+        if (pe_uniform) host[1] *= round_dt(s->logical[2], s->mass_value * s->mass_value);
+        // -G * sum: a Python scalar MULTIPLYING a half tensor stays in float (torch opmath; only added scalars are
+        // rounded to the tensor's dtype first)
+        *potential = round_dt(t, round_dt(is_half(t) ? NB_F32 : t, -c.G) * round_dt(t, host[1]));
         // the reference multiplies by the triu mask before dividing by dist (simulation.py:189): the masked
         // entries are 0 / dist = NaN where dist == 0, i.e. on the whole diagonal when the softening rounds to
         // zero in the positions' dtype (softening 0; 1e-4 with float16 positions).  dist > 0 otherwise.

@@ -36,6 +36,8 @@ What is captured:
       grid modes (INT8 / INT4 / CUSTOM) on fp64 state, grid modes on float16 / bfloat16 state.
   G20 quant-bin CHECKSUMS per target row (sum k, sum k * ((j mod 65521) + 1)) from the reference's bin matrices on the
       stored g13 / g16 positions: what nb_quant_bin_sums reads out of the production pair loops.
+  G21 the reference against ITSELF under a reversed summation order (its own code on the flipped particle order): noise
+      floor of the grid-mode trajectories (N = 1024 / 4096, three steps) and of INT8 / INT4 on half-typed state.
   G7  half-typed state (float16 / bfloat16 tensors) through the cast modes and FLOAT64: energies before
       and after the promotion, state after three steps.
 
@@ -947,6 +949,108 @@ def g20():
     print("G20 done")
 
 
+class FlippedOrder(ref_sim.GalaxySimulation):
+    """The reference against ITSELF under another summation order: the stock _compute_accelerations (its own code,
+    nothing restated) is handed the particles in reversed order and the result is flipped back.  Every pair's
+    arithmetic is unchanged (r2, hooks and the global grid bounds are symmetric in the particle order); only the order
+    in which torch's sum(dim=1) meets the sources differs -- the rounding-level freedom any other correct
+    implementation has too ("reduction order unspecified")."""
+
+    def _compute_accelerations(self):
+        p, m = self.positions, self.masses
+        self.positions, self.masses = p.flip(0), m.flip(0)
+        try:
+            a = super()._compute_accelerations()
+        finally:
+            self.positions, self.masses = p, m
+        return a.flip(0)
+
+
+def g21():
+    """Noise floor of the REFERENCE against itself for the two parity bars that round 2 widened after red runs
+    (VERDICT r2 weak #2): what the reference does when only its summation order changes.
+      traj/*  three leapfrog steps of the grid modes at N = 4096 (g13's disk galaxy) and N = 1024 (g2's): fraction of
+              particles whose velocity differs by more than 2e-6 of max|v|, the maximum and the 99.9 % quantile; the
+              stock run's final state is stored too, so the HIP path is compared with the reference itself.
+      half/*  INT8 / INT4 on float16 / bfloat16 state (g15's system + 7 more seeds of the same recipe): fraction of
+              force values that differ by more than half a force-grid step between the two summation orders."""
+    out = {}
+    cases = []
+    g = np.load(os.path.join(OUT, "g13_bins_n4096_d2.npz"))
+    cases.append(("n4096", *(torch.from_numpy(g[k]).clone() for k in ("pos", "vel", "mass"))))
+    g = np.load(os.path.join(OUT, "g2_config1_n1024.npz"))
+    cases.append(("n1024", *(torch.from_numpy(g[k]).clone() for k in ("pos", "vel", "mass"))))
+    for name, pos, vel, mass in cases:
+        for mode in (PrecisionMode.CUSTOM, PrecisionMode.INT8_SIM, PrecisionMode.INT4_SIM):
+            kw = dict(precision_mode=mode, G=0.001, softening=0.1, dt=0.01, device=torch.device("cpu"))
+            a = ref_sim.GalaxySimulation(pos.clone(), vel.clone(), mass.clone(), **kw)
+            b = FlippedOrder(pos.clone(), vel.clone(), mass.clone(), **kw)
+            tag = f"traj/{name}/{mode.value}"
+            out[f"{tag}/acc0_relerr"] = np.float64((a.accelerations - b.accelerations).abs().max() / a.accelerations.abs().max())
+            for _ in range(3):
+                a.step()
+                b.step()
+            va, vb = a.velocities.double(), b.velocities.double()
+            err = ((va - vb).abs().max(dim=1).values / va.abs().max()).numpy()
+            out[f"{tag}/vel_frac_gt_2e-6"] = np.float64((err > 2e-6).mean())
+            out[f"{tag}/vel_max"] = np.float64(err.max())
+            out[f"{tag}/vel_q999"] = np.float64(np.quantile(err, 0.999))
+            out[f"{tag}/pos_relerr"] = np.float64((a.positions.double() - b.positions.double()).abs().max() / a.positions.abs().max())
+            ea, eb = a.get_total_energy(), b.get_total_energy()
+            out[f"{tag}/energy_relerr"] = np.float64(abs(ea - eb) / abs(ea))
+            out[f"{tag}/pos3"], out[f"{tag}/vel3"] = npy(a.positions), npy(a.velocities)
+            out[f"{tag}/energy3"] = np.float64(ea)
+            # ... and against itself on LAST-BIT-PERTURBED initial positions: a share `f` of the coordinates moved by one
+            # fp32 ulp (seeded).  That is what any implementation whose fp32 force sums are not bit-identical to torch's
+            # looks like after its first kick + drift: a rounding-level difference in a few coordinates, after which a
+            # pair sitting on a bin edge lands in the neighbouring bin on one side of the comparison.
+            for f in (0.02, 1.0):
+                gen = torch.Generator().manual_seed(2100 + int(f * 100))
+                sel = torch.rand(pos.shape, generator=gen) < f
+                sign = torch.where(torch.rand(pos.shape, generator=gen) < 0.5, -1, 1).to(torch.int32)
+                bits = pos.clone().view(torch.int32)
+                # one ulp up or down in magnitude (sign-magnitude integers: +-1 on the bit pattern)
+                pert = torch.where(sel, bits + sign, bits).view(torch.float32)
+                c = ref_sim.GalaxySimulation(pert, vel.clone(), mass.clone(), **kw)
+                for _ in range(3):
+                    c.step()
+                vc = c.velocities.double()
+                errc = ((va - vc).abs().max(dim=1).values / va.abs().max()).numpy()
+                ft = f"{tag}/ulp{int(f * 100)}"
+                out[f"{ft}/vel_frac_gt_2e-6"] = np.float64((errc > 2e-6).mean())
+                out[f"{ft}/vel_max"] = np.float64(errc.max())
+                out[f"{ft}/vel_q999"] = np.float64(np.quantile(errc, 0.999))
+                out[f"{ft}/pos_relerr"] = np.float64((a.positions.double() - c.positions.double()).abs().max() / a.positions.abs().max())
+                out[f"{ft}/energy_relerr"] = np.float64(abs(ea - c.get_total_energy()) / abs(ea))
+                print("G21", ft, "frac", out[f"{ft}/vel_frac_gt_2e-6"], "max", out[f"{ft}/vel_max"], "q999", out[f"{ft}/vel_q999"],
+                      "E", out[f"{ft}/energy_relerr"])
+            print("G21", tag, "frac", out[f"{tag}/vel_frac_gt_2e-6"], "max", out[f"{tag}/vel_max"], "q999", out[f"{tag}/vel_q999"],
+                  "pos", out[f"{tag}/pos_relerr"], "E", out[f"{tag}/energy_relerr"])
+    seeds = [15, 101, 102, 103, 104, 105, 106, 107]           # 15 = g15's system
+    out["half/seeds"] = np.array(seeds)
+    for si, seed in enumerate(seeds):
+        pos, vel, mass = make_ics(193, 2, seed, True)
+        out[f"half/ics{si}/pos"], out[f"half/ics{si}/vel"], out[f"half/ics{si}/mass"] = npy(pos), npy(vel), npy(mass)
+        for grp, cast in (("half", lambda t: t.half()), ("bf16", lambda t: t.bfloat16())):
+            for mode in (PrecisionMode.INT8_SIM, PrecisionMode.INT4_SIM):
+                kw = dict(precision_mode=mode, G=0.001, softening=0.1, dt=0.01, device=torch.device("cpu"))
+                with Spy() as spy:
+                    a = ref_sim.GalaxySimulation(cast(pos), cast(vel), cast(mass), **kw)
+                b = FlippedOrder(cast(pos), cast(vel), cast(mass), **kw)
+                fin, flv, fout = spy.lin[0]
+                step = (float(fin.max()) - float(fin.min())) / (flv - 1)
+                diff = (a.accelerations.double() - b.accelerations.double()).abs().numpy()
+                tag = f"half/{grp}/{mode.value}/{si}"
+                out[f"{tag}/acc0"] = npy(a.accelerations.double())
+                out[f"{tag}/step"] = np.float64(step)
+                out[f"{tag}/frac_gt_half_step"] = np.float64((diff > 0.5 * step).mean())
+                out[f"{tag}/max_in_steps"] = np.float64(diff.max() / step)
+        print("G21 half seed", seed, {k.split("/", 1)[1]: float(v) for k, v in out.items()
+                                      if k.endswith(f"/{si}/frac_gt_half_step")})
+    np.savez_compressed(os.path.join(OUT, "g21_reference_self_noise.npz"), **out)
+    print("G21 done")
+
+
 def g14():
     """The reference's own state hash (reproducibility.py:227-232) on golden states."""
     import reproducibility as ref_repro
@@ -964,6 +1068,6 @@ def g14():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
+    which = sys.argv[1:] or ["g1", "g1c", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
     for w in which:
         globals()[w]()

@@ -1184,28 +1184,70 @@ def test_grid_modes_trajectory_on_symmetric_path(nb, mode):
     ref.run(3)
     assert sim.force_kernel_name() == "force_sym_kernel<float"
     v, v_ref = sim.velocities.numpy().astype(np.float64), ref.velocities.astype(np.float64)
+    noise = load_golden("g21_reference_self_noise.npz")
     if mode == "custom":
         # The table-free pair path reproduces the accelerations to ~2e-7 (bins are identical for identical
         # positions); once a position differs in its last bit, a pair sitting on a bin edge can land in the
         # neighbouring bin of this 64-level grid (a 33 % jump of that pair's factor) -- on either side of the
-        # comparison, exactly as the reference does against itself under another summation order (SURVEY.md
-        # section 8c: particle-level parity of the grid modes is statistical).  Flips must stay isolated and small.
+        # comparison.  The REFERENCE does exactly that against itself when its initial positions move by one fp32 ulp
+        # (golden g21, N = 4096: 0.098 % of the particles beyond 2e-6, max 4.1e-6): the share of such particles is held
+        # to twice the reference's own; one flipped pair cannot move a velocity by more than 0.33 x the largest
+        # softened pair acceleration (0.385 G m / eps^2) x dt / 2 per half kick.
         err = np.abs(v - v_ref).max(axis=1) / np.abs(v_ref).max()
-        print(f"custom 3 steps: max {err.max():.2e}, particles above 2e-6: {(err > 2e-6).sum()} of {err.size}")
-        assert np.quantile(err, 0.999) < 2e-6
-        assert err.max() < 1e-4
+        ref_frac = max(float(noise[f"traj/{c}/custom/ulp100/vel_frac_gt_2e-6"]) for c in ("n4096", "n1024"))
+        print(f"custom 3 steps: max {err.max():.2e}, particles above 2e-6: {(err > 2e-6).sum()} of {err.size} "
+              f"(reference against itself: {ref_frac:.2e})")
+        assert (err > 2e-6).mean() <= 2 * ref_frac
+        one_flip = 0.33 * 0.385 * 0.001 * 1.0 / 0.1 ** 2 * 0.005 / np.abs(v_ref).max()
+        assert err.max() <= 2 * one_flip
     else:
         # int8 snaps the summed forces to a 256-level grid: a value on a rounding boundary may land in the
         # neighbouring bin (fp32 summation order), which moves that velocity component by step*dt/2 per half kick.
-        # Such flips must stay isolated and bounded by the six half kicks of three steps.
+        # Such flips must stay isolated (share of particles: twice the reference's own under a one-ulp perturbation of
+        # its initial positions, golden g21) and bounded by the six half kicks of three steps.
         _, dbg = O.accelerations(pos.numpy(), mass.numpy(), mode, debug=True)
         step = (dbg["fmax"] - dbg["fmin"]) / 255
         dv = np.abs(v - v_ref)
+        ref_frac = max(float(noise[f"traj/{c}/int8_sim/ulp100/vel_frac_gt_2e-6"]) for c in ("n4096", "n1024"))
+        frac = (dv.max(axis=1) > 2e-6 * np.abs(v_ref).max()).mean()
+        print(f"int8 3 steps: particles above 2e-6: {frac:.2e} (reference against itself: {ref_frac:.2e})")
         assert dv.max() <= 6 * step * 0.01 / 2 * 1.5
-        assert (dv.max(axis=1) > 2e-6 * np.abs(v_ref).max()).mean() < 2e-3
+        assert frac <= max(2 * ref_frac, 2.0 / dv.shape[0])
     assert relerr(sim.positions.numpy(), ref.positions) < 2e-6
     e, e_ref = sim.get_total_energy(), ref.get_total_energy()
     assert abs(e - e_ref) <= 2e-5 * abs(e_ref)
+
+
+@pytest.mark.parametrize("mode", ["custom", "int8_sim", "int4_sim"])
+@pytest.mark.parametrize("case", ["n4096", "n1024"])
+def test_grid_mode_trajectories_vs_reference_within_its_own_noise(nb, case, mode):
+    """Three leapfrog steps of the grid modes against the REFERENCE's own final state (golden g21: N = 4096 disk galaxy
+    of g13, N = 1024 of config 1), with bars taken from what the reference does against ITSELF (same fixture): under a
+    reversed summation order it reproduces itself to 1.2e-7 (its fp32 sums are nearly order-independent); with every
+    initial coordinate moved by one fp32 ulp -- the state any implementation whose fp32 sums are not bit-identical to
+    torch's is in after its first drift -- isolated particles jump (pairs crossing a distance-bin edge, force values
+    crossing a force-bin edge).  Asserted: the share of particles beyond 2e-6 of max|v| and the largest deviation stay
+    within TWICE the reference's own figures (floors: two particles -- one flipped pair touches two -- and the fp32
+    single-evaluation bar 2e-6); positions and energy alike."""
+    noise = load_golden("g21_reference_self_noise.npz")
+    g = load_golden("g13_bins_n4096_d2.npz" if case == "n4096" else "g2_config1_n1024.npz")
+    sim = nb.GalaxySimulation(T(g["pos"]), T(g["vel"]), T(g["mass"]), precision_mode=nb.PrecisionMode(mode),
+                              G=0.001, softening=0.1, dt=0.01)
+    sim.run(3)
+    tag = f"traj/{case}/{mode}"
+    v_ref = noise[f"{tag}/vel3"].astype(np.float64)
+    v = sim.velocities.numpy().astype(np.float64)
+    err = np.abs(v - v_ref).max(axis=1) / np.abs(v_ref).max()
+    frac, worst = float((err > 2e-6).mean()), float(err.max())
+    ref_frac = float(noise[f"{tag}/ulp100/vel_frac_gt_2e-6"])
+    ref_max = float(noise[f"{tag}/ulp100/vel_max"])
+    print(f"{tag}: particles beyond 2e-6: {frac:.2e} (reference vs itself {ref_frac:.2e}), max {worst:.2e} "
+          f"(reference vs itself {ref_max:.2e}), kernel {sim.force_kernel_name()}")
+    assert frac <= max(2 * ref_frac, 2.0 / err.size)
+    assert worst <= max(2 * ref_max, 2e-6)
+    assert relerr(sim.positions.numpy(), noise[f"{tag}/pos3"]) <= max(2 * float(noise[f"{tag}/ulp100/pos_relerr"]), 2e-6)
+    e_ref = float(noise[f"{tag}/energy3"])
+    assert abs(sim.get_total_energy() - e_ref) <= max(2 * float(noise[f"{tag}/ulp100/energy_relerr"]), 2e-6) * abs(e_ref)
 
 
 @pytest.mark.parametrize("L,sym", [(512, 0), (1000, 1), (4096, 0), (4096, 1)])
@@ -1754,9 +1796,10 @@ def test_g15_dtype_combinations_vs_reference(nb, tag):
     sim = nb.GalaxySimulation(pos, vel, mass, precision_mode=nb.PrecisionMode(mode), G=0.001, softening=0.1, dt=0.01)
     names = lambda: [str(t.dtype) for t in (sim.positions, sim.velocities, sim.masses, sim.accelerations)]
     assert names() == list(g[f"{tag}/dtypes0"])
+    # (round 2 allowed 4e-3 / 2e-2 on half-typed state: the generic kernel rounded the scalars G and levels - 1 to the
+    # half type, which torch does not do for scalars that multiply or divide -- root-caused in round 3; the half-typed
+    # chains now meet the same fp32 bar as everything else)
     tol = 1e-12 if grp == "all64" else 2e-6
-    if grp in ("half", "bf16"):
-        tol = 2e-2 if grp == "bf16" else 4e-3      # half-precision pair arithmetic: one ulp of the type per operation
     acc = sim.accelerations.double().numpy()
     ref = g[f"{tag}/acc0"]
     if mode in ("int8_sim", "int4_sim") and f"{tag}/fmin" in g.files:
@@ -1764,8 +1807,16 @@ def test_g15_dtype_combinations_vs_reference(nb, tag):
         step = (float(g[f"{tag}/fmax"]) - float(g[f"{tag}/fmin"])) / (levels - 1)
         diff = np.abs(acc - ref)
         assert diff.max() <= 1.01 * step + tol * np.abs(ref).max()
-        # half-typed pair arithmetic perturbs the summed forces by ~1e-3, comparable to a 256-level force-grid step
-        assert (diff > 0.5 * step).mean() < (0.1 if grp in ("half", "bf16") else 0.02)
+        frac = float((diff > 0.5 * step).mean())
+        print(f"{tag}: force values in a neighbouring force bin: {frac:.4f}")
+        if grp in ("half", "bf16"):
+            # the bar is the REFERENCE's own figure under a reversed summation order (golden g21: 0 ... 0.26 % over
+            # eight systems of this recipe), doubled, and never below two values
+            noise = load_golden("g21_reference_self_noise.npz")
+            ref_frac = max(float(noise[f"half/{grp}/{mode}/{si}/frac_gt_half_step"]) for si in range(8))
+            assert frac <= max(2 * ref_frac, 2.0 / diff.size), (frac, ref_frac)
+        else:
+            assert frac < 0.02
     else:
         assert relerr(acc, ref) < tol, relerr(acc, ref)
     ke, pe = sim.get_kinetic_energy(), sim.get_potential_energy()
@@ -1776,7 +1827,7 @@ def test_g15_dtype_combinations_vs_reference(nb, tag):
     assert names() == list(g[f"{tag}/dtypes3"])
     ptol = tol if mode not in ("int8_sim", "int4_sim") else max(tol, 1e-4)      # force-bin flips: dt^2 * one grid step
     assert relerr(sim.positions.double().numpy(), g[f"{tag}/pos3"]) < ptol
-    assert relerr(sim.velocities.double().numpy(), g[f"{tag}/vel3"]) < max(ptol, 10 * tol if grp in ("half", "bf16") else ptol)
+    assert relerr(sim.velocities.double().numpy(), g[f"{tag}/vel3"]) < ptol
 
 
 def test_custom_levels_beyond_the_tables(nb):

@@ -468,6 +468,59 @@ def test_g20_bin_checksums_vs_reference(fname, mode):
     assert np.array_equal((k * w[None, :]).sum(axis=1), ref[f"g13_{case}/{mode}/s2"])
 
 
+def test_torch_scalar_semantics_on_half_tensors():
+    """What the oracle's scalar_as / scalar_mul (nbody_oracle.c) encode, measured on torch itself (no reference code
+    involved): a Python scalar ADDED to a half tensor is rounded to the tensor's dtype first; a Python scalar that
+    MULTIPLIES / DIVIDES one stays in float; G / t is t.reciprocal() times float(G)."""
+    import torch
+    torch.manual_seed(0)
+    for dt in (torch.float16, torch.bfloat16):
+        x = (torch.rand(50000) * 10 + 0.1).to(dt)
+        f = x.float()
+        assert torch.equal(x * 0.001, (f * np.float32(0.001)).to(dt))
+        assert not torch.equal(x * 0.001, (f * torch.tensor(0.001).to(dt).float()).to(dt))
+        assert torch.equal(x / 3.3, (f / np.float32(3.3)).to(dt))
+        assert torch.equal(0.001 / x, (x.reciprocal().float() * np.float32(0.001)).to(dt))
+        y = (torch.rand(50000) * 0.05).to(dt)
+        assert torch.equal(y + 0.0123, (y.float() + torch.tensor(0.0123).to(dt).float()).to(dt))
+        assert not torch.equal(y + 0.0123, (y.float() + np.float32(0.0123)).to(dt))
+
+
+_G15_HALF = [(grp, mode) for grp in ("half", "bf16") for mode in ("int8_sim", "int4_sim", "custom")]
+
+
+@pytest.mark.parametrize("grp,mode", _G15_HALF)
+def test_g15_grid_modes_on_half_typed_state_vs_reference(grp, mode):
+    """The grid modes on float16 / bfloat16 state tensors (g15: the stock class accepts them): every op of
+    quantization.py:106-127 rounds to the half type.  With the scalar semantics above the oracle reproduces the
+    reference's forces to fp32 summation level -- before round 3 both the oracle and the HIP path rounded G and
+    (levels - 1) to the half type first and sat 4e-4 away, which the 4e-3 bar of round 2 hid (VERDICT r2 weak #2)."""
+    g = load_golden("g15_dtype_combos.npz")
+    tag = f"{grp}/{mode}"
+    assert int(g[f"{tag}/ok"]) == 1
+    code = O.F16 if grp == "half" else O.BF16
+    import torch
+    cast = (lambda a: torch.from_numpy(a).half().float().numpy()) if grp == "half" else \
+           (lambda a: torch.from_numpy(a).bfloat16().float().numpy())
+    pos, mass = cast(g["pos"]), cast(g["mass"])
+    acc, dbg = O.accelerations(pos, mass, mode, softening=0.1, debug=True, pos_code=code, mass_code=code)
+    ref = g[f"{tag}/acc0"]
+    if mode == "custom":
+        assert relerr(acc, ref) < 2e-6, relerr(acc, ref)
+    else:
+        levels = 256 if mode == "int8_sim" else 16
+        step = (float(g[f"{tag}/fmax"]) - float(g[f"{tag}/fmin"])) / (levels - 1)
+        diff = np.abs(np.asarray(acc, np.float64) - ref)
+        frac = float((diff > 0.5 * step).mean())
+        print(f"{tag}: force values off by more than half a grid step: {frac:.4f}, max {diff.max() / step:.3f} steps")
+        assert abs(dbg["fmin"] - float(g[f"{tag}/fmin"])) <= 2e-6 * abs(float(g[f"{tag}/fmin"]))
+        assert abs(dbg["fmax"] - float(g[f"{tag}/fmax"])) <= 2e-6 * abs(float(g[f"{tag}/fmax"]))
+        noise = load_golden("g21_reference_self_noise.npz")
+        ref_frac = max(float(noise[f"half/{grp}/{mode}/{si}/frac_gt_half_step"]) for si in range(8))
+        assert frac <= max(2 * ref_frac, 2.0 / diff.size), (frac, ref_frac)
+        assert diff.max() <= 1.01 * step
+
+
 def test_g14_state_hash_matches_reference():
     """checkpoint.state_hash against hashes produced by the reference's reproducibility.hash_tensor_state."""
     import json
