@@ -125,8 +125,10 @@ int ensure_storage(nb_sim *s, bool f64)
     if (!f64 && grid_mode(s->cfg.mode)) {
         HIPCHK(hipMalloc((void **)&s->prune_cand, cnt * sizeof(float)));
         HIPCHK(hipMalloc((void **)&s->prune_rho, (size_t)s->cfg.n * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&s->prune_idx, (size_t)s->cfg.n * sizeof(int)));
         HIPCHK(hipMalloc((void **)&s->prune_state, sizeof(PruneState)));
-        const PruneState init = {{0xffffffffu, 0xffffffffu, 0xffffffffu}, {0u, 0u, 0u}, 0ull, {0ull, 0ull}, 0, 0};
+        PruneState init{};
+        for (int k = 0; k < 3; ++k) { init.box_min[k] = 0xffffffffu; init.box_max[k] = 0u; }
         HIPCHK(hipMemcpy(s->prune_state, &init, sizeof init, hipMemcpyHostToDevice));
     }
     HIPCHK(hipMemsetAsync(s->acc, 0, cnt * el, s->stream));
@@ -244,7 +246,7 @@ int nb_destroy(nb_sim *s)
                     (void *)s->scratch, (void *)s->scalars, (void *)s->fbins, (void *)s->sym.work,
                     (void *)s->sym.row_slot0, (void *)s->sym.row_nslots, (void *)s->sym.col_upto,
                     (void *)s->sym.packed, (void *)s->sym.rowslab, (void *)s->sym.colslab,
-                    (void *)s->prune_cand, (void *)s->prune_rho, (void *)s->prune_state, s->metrics_scratch, s->gen_scalars, s->pos_alt, (void *)s->small_part,
+                    (void *)s->prune_cand, (void *)s->prune_rho, (void *)s->prune_idx, (void *)s->prune_state, s->metrics_scratch, s->gen_scalars, s->pos_alt, (void *)s->small_part,
                     (void *)s->sums64, (void *)s->bin_out})
         if (p) (void)hipFree(p);
     if (s->prof_init)
@@ -274,7 +276,12 @@ int nb_set_state(nb_sim *s, const void *pos, const void *vel, const void *mass, 
     if (dtype == NB_F64 && !s->is_f64)
         return fail(NB_ERR_UNSUPPORTED, "cannot upload fp64 data into fp32 state storage: create the handle with "
                                         "NB_FLAG_F64_STORAGE when any of positions / velocities / masses is fp64");
-    if (pos) { if (int rc = upload(s, pos, dtype, on_device, s->pos, nd(s))) return rc; s->logical[0] = dtype; s->have_pos = true; }
+    if (pos) {
+        if (int rc = upload(s, pos, dtype, on_device, s->pos, nd(s))) return rc;
+        s->logical[0] = dtype;
+        s->have_pos = true;
+        s->prune_seeded = false;         // new positions: the next grid evaluation searches its farthest pair from scratch
+    }
     if (vel) { if (int rc = upload(s, vel, dtype, on_device, s->vel, nd(s))) return rc; s->logical[1] = dtype; s->have_vel = true; }
     if (mass) {
         if (int rc = upload(s, mass, dtype, on_device, s->mass, s->cfg.n)) return rc;

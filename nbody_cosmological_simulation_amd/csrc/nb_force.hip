@@ -511,6 +511,10 @@ prune_rho_kernel(const float *__restrict__ pos, int n, float *__restrict__ rho, 
 {
     const int i = blockIdx.x * NB_BLOCK + threadIdx.x;
     unsigned long long key = 0ull;
+    if (i == 0) {            // the centre stays put for the tracked searches that follow (PruneState::c)
+#pragma unroll
+        for (int k = 0; k < D; ++k) ps->c[k] = 0.5f * order_unkey(ps->box_min[k]) + 0.5f * order_unkey(ps->box_max[k]);
+    }
     if (i < n) {
         float s = 0.0f;
 #pragma unroll
@@ -800,7 +804,18 @@ __device__ __forceinline__ void grid_tables_body(GridTables *__restrict__ tab, i
         maxrel = s_red[0];
     }
     if (fin && ps) {
-        // the pruned max-r2 search is finished: reset its scratch for the next evaluation
+        // the pruned max-r2 search is finished: seed the tracked search of the next evaluation with its far pair
+        // (the second hop's pair g -> h is a real pair; the exact maximum is re-derived from the positions then) ...
+        ps->pair_i = (int)(ps->lb[0] & 0xffffffffull);
+        ps->pair_j = (int)(ps->lb[1] & 0xffffffffull);
+        ps->rho_m = __uint_as_float((unsigned int)(ps->far >> 32)) * 1.005f;
+        ps->rho_prev = 0.0f;
+        ps->seeded = (ps->nan_flag == 0) ? 1 : 0;
+        ps->rho_cur = 0u;
+        ps->scan_done = 0u;
+        ps->best_i = 0ull;
+        ps->best_j = 0ull;
+        // ... and reset its scratch
         for (int c = 0; c < 3; ++c) { ps->box_min[c] = 0xffffffffu; ps->box_max[c] = 0u; }
         ps->far = 0ull;
         ps->lb[0] = 0ull;
@@ -937,6 +952,179 @@ r2max_tables_kernel(const float *__restrict__ pos, ForceGeom g, float eps2, Grid
     }
     __syncthreads();
     if (!s_mine) return;
+    grid_tables_body<true>(tab, levels, G, eps2, min_val, nullptr, allow_fast, s_bits);
+}
+
+// ------------------------------------------------------------------------------------------
+// Tracked max-r2 search (round 3): two launches per evaluation instead of six (+ tables).
+// Exactness argument as for the pruned search above, with the lower bound LB taken from the far pair of the LAST
+// evaluation re-evaluated at the new positions, a fixed centre c, and rho_M = (last measured rho_max) + twice its last
+// growth + 1e-4 of it as the bound on every rho: both members of the maximal pair satisfy rho >= sqrt(LB - eps2) - rho_M.  The filter pass
+// measures the actual rho_max; if it exceeds rho_M (a particle left the margin) the scan simply takes ALL particles
+// -- slower, still exact.  NaN coordinates poison the maximum exactly as torch's max() does.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(NB_BLOCK)
+track_filter_kernel(const float *__restrict__ pos, int n, float eps2, float *__restrict__ cand, int *__restrict__ cand_idx,
+                    PruneState *__restrict__ ps)
+{
+    __shared__ float s_need;
+    __shared__ unsigned int s_rho[NB_BLOCK / 64];
+    __shared__ int s_nan;
+    if (threadIdx.x == 0) {
+        float d[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) d[k] = __fsub_rn(pos[(size_t)ps->pair_j * D + k], pos[(size_t)ps->pair_i * D + k]);
+        const float lb = r2_f32_exact<D>(d, eps2);
+        s_need = sqrtf(fmaxf(lb - eps2, 0.0f)) * (1.0f - 1e-5f) - ps->rho_m * (1.0f + 1e-5f);
+        s_nan = 0;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * NB_BLOCK + threadIdx.x;
+    unsigned int rb = 0u;
+    if (i < n) {
+        float x[D], s = 0.0f;
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            x[k] = pos[(size_t)i * D + k];
+            bad |= (x[k] != x[k]);
+            const float d = x[k] - ps->c[k];
+            s += d * d;
+        }
+        const float r = sqrtf(s);
+        if (bad) s_nan = 1;
+        else rb = __float_as_uint(r);              // r >= 0 (or +inf): bit patterns order like the values
+        if (!bad && r * (1.0f + 1e-5f) >= s_need) {
+            const int slot = atomicAdd(&ps->count, 1);
+#pragma unroll
+            for (int k = 0; k < D; ++k) cand[(size_t)slot * D + k] = x[k];
+            cand_idx[slot] = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) rb = max(rb, (unsigned int)__shfl_xor((int)rb, off, 64));
+    if ((threadIdx.x & 63) == 0) s_rho[threadIdx.x >> 6] = rb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int m = s_rho[0];
+#pragma unroll
+        for (int w = 1; w < NB_BLOCK / 64; ++w) m = max(m, s_rho[w]);
+        atomicMax(&ps->rho_cur, m);
+        if (s_nan) atomicOr(&ps->nan_flag, 1);
+    }
+}
+
+constexpr int NB_TRACK_BLOCKS = 128;     // scan workgroups: every one ends in up to three same-address atomics (~17 ns each)
+
+template <int D>
+__global__ void __launch_bounds__(NB_BLOCK)
+track_scan_kernel(const float *__restrict__ pos, const float *__restrict__ cand, const int *__restrict__ cand_idx, int n,
+                  float eps2, PruneState *__restrict__ ps, GridTables *__restrict__ tab, int levels, float G, float min_val,
+                  int allow_fast, int fuse_tables)
+{
+    static_assert(NB_BLOCK == NB_LUT_MIN, "the last workgroup runs the single-block tables code");
+    __shared__ float sj[D][NB_TJ];
+    __shared__ int sji[NB_TJ];
+    __shared__ unsigned long long s_ki[NB_BLOCK / 64], s_kj[NB_BLOCK / 64];
+    __shared__ unsigned int s_bits;
+    __shared__ int s_mine;
+    const int tid = threadIdx.x;
+    // the filter pass measured the real rho_max: inside the assumed bound the candidates are complete, else take everyone
+    const bool valid = ps->rho_cur <= __float_as_uint(ps->rho_m);
+    const int m = valid ? ps->count : n;
+    const float *src = valid ? cand : pos;
+    const int T = (m + NB_TJ - 1) / NB_TJ;
+    const long long npairs = (long long)T * (T + 1) / 2;        // tile pairs (it <= jt), row-major
+    unsigned long long best_i = 0ull, best_j = 0ull;
+    for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
+        // p -> (it, jt): rows of lengths T, T - 1, ...; first[it] = it * T - it * (it - 1) / 2
+        const double tt = 2.0 * T + 1.0;
+        int it = (int)((tt - sqrt(tt * tt - 8.0 * (double)p)) * 0.5);
+        it = max(0, min(it, T - 1));
+        while (it > 0 && (long long)it * T - (long long)it * (it - 1) / 2 > p) --it;
+        while ((long long)(it + 1) * T - (long long)(it + 1) * it / 2 <= p) ++it;
+        const int jt = it + (int)(p - ((long long)it * T - (long long)it * (it - 1) / 2));
+        const int i = min(it * NB_TJ + tid, m - 1), j = min(jt * NB_TJ + tid, m - 1);
+        float xi[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xi[k] = src[(size_t)i * D + k];
+        const int ii = valid ? cand_idx[i] : i;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < D; ++k) sj[k][tid] = src[(size_t)j * D + k];
+        sji[tid] = valid ? cand_idx[j] : j;
+        __syncthreads();
+        const int cnt = min(NB_TJ, m - jt * NB_TJ);
+        unsigned int best = 0u;
+        int bj = 0;
+#pragma unroll 8
+        for (int jj = 0; jj < cnt; ++jj) {
+            float d[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) d[k] = __fsub_rn(sj[k][jj], xi[k]);
+            const unsigned int b = r2_order_bits(r2_f32_exact<D>(d, eps2));
+            bj = b > best ? jj : bj;
+            best = max(best, b);
+        }
+        const unsigned long long ki = ((unsigned long long)best << 32) | (unsigned int)ii;
+        const unsigned long long kj = ((unsigned long long)best << 32) | (unsigned int)sji[bj];
+        if (ki > best_i) { best_i = ki; best_j = kj; }
+    }
+    // block maximum; the partner index travels with the lane that holds the maximum
+    {
+        unsigned long long ki = best_i, kj = best_j;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long oi = __shfl_xor(ki, off, 64), oj = __shfl_xor(kj, off, 64);
+            if (oi > ki) { ki = oi; kj = oj; }
+        }
+        if ((tid & 63) == 0) { s_ki[tid >> 6] = ki; s_kj[tid >> 6] = kj; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long ki = s_ki[0], kj = s_kj[0];
+#pragma unroll
+        for (int w = 1; w < NB_BLOCK / 64; ++w)
+            if (s_ki[w] > ki) { ki = s_ki[w]; kj = s_kj[w]; }
+        if (ki) {
+            // two independent maxima: on an exact tie of r2 they may name particles of different pairs -- harmless, the
+            // pair only provides the next evaluation's lower bound, which is re-evaluated from the positions
+            atomicMax(&ps->best_i, ki);
+            atomicMax(&ps->best_j, kj);
+        }
+        __threadfence();
+        s_mine = (atomicAdd(&ps->scan_done, 1u) == gridDim.x - 1) ? 1 : 0;
+        if (s_mine) {
+            const unsigned long long fi = atomicMax(&ps->best_i, 0ull), fj = atomicMax(&ps->best_j, 0ull);
+            unsigned int bits = (unsigned int)(fi >> 32);
+            if (m <= 0) bits = 0u;
+            if (ps->nan_flag) bits = 0x7fc00000u;                 // a NaN coordinate: torch's max() would be NaN
+            // a single particle (or none scanned): the diagonal pair r2 = eps2 is the maximum
+            if (bits == 0u) bits = r2_order_bits(eps2);
+            s_bits = bits;
+            // next evaluation: this maximum's pair, the measured rho_max plus margin, clean counters
+            if (fi) { ps->pair_i = (int)(fi & 0xffffffffull); ps->pair_j = (int)(fj & 0xffffffffull); }
+            {
+                // margin for the next evaluation: twice the growth rho_max showed over this step (an escaper keeps its
+                // speed) + 1e-4 relative; the first tracked evaluation has no growth figure yet and keeps 0.5 %
+                const float rc = __uint_as_float(ps->rho_cur);
+                const float grow = (ps->rho_prev > 0.0f) ? fmaxf(rc - ps->rho_prev, 0.0f) : 0.0025f * rc;
+                ps->rho_m = rc + 2.0f * grow + 1e-4f * rc;
+                ps->rho_prev = rc;
+            }
+            ps->seeded = (ps->nan_flag == 0) ? 1 : 0;
+            ps->rho_cur = 0u;
+            ps->count = 0;
+            ps->nan_flag = 0;
+            ps->best_i = 0ull;
+            ps->best_j = 0ull;
+            ps->scan_done = 0u;
+            if (!fuse_tables) tab->r2max_bits = bits;            // the multi-block tables kernel follows
+        }
+    }
+    __syncthreads();
+    if (!s_mine || !fuse_tables) return;
     grid_tables_body<true>(tab, levels, G, eps2, min_val, nullptr, allow_fast, s_bits);
 }
 
@@ -1110,6 +1298,20 @@ hipError_t nb_launch_r2max_pruned(const float *pos, int n, int dim, float eps2, 
         hipLaunchKernelGGL((prune_hop_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, pos, n, eps2, &ps->lb[0], &ps->lb[1]);
         hipLaunchKernelGGL((prune_compact_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, pos, rho, n, eps2, cand, ps);
         hipLaunchKernelGGL((prune_scan_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, cand, eps2, ps, tab);
+        return hipGetLastError();
+    });
+}
+
+hipError_t nb_launch_r2max_tracked(const float *pos, int n, int dim, float eps2, float *cand, int *cand_idx, PruneState *ps,
+                                   GridTables *tab, int levels, float G, float min_val, int allow_fast, hipStream_t st)
+{
+    const int blocks = (n + NB_BLOCK - 1) / NB_BLOCK;
+    const int fuse = levels <= NB_LUT_MIN ? 1 : 0;
+    return dispatch_dim(dim, [&](auto D) {
+        constexpr int DD = decltype(D)::value;
+        hipLaunchKernelGGL((track_filter_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, pos, n, eps2, cand, cand_idx, ps);
+        hipLaunchKernelGGL((track_scan_kernel<DD>), dim3(NB_TRACK_BLOCKS), dim3(NB_BLOCK), 0, st, pos, cand, cand_idx, n, eps2, ps,
+                           tab, levels, G, min_val, allow_fast, fuse);
         return hipGetLastError();
     });
 }

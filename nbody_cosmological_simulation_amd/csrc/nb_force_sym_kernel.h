@@ -10,6 +10,18 @@
 #else
 #define NB_GRID_R2_EXACT_V 0
 #endif
+// Table-free pair path, force factor of a pair whose bin the estimate settled: 0 = v_exp_f32((k - kc) c1 + c0c) (round 2:
+// no LDS access at all), 1 = the table entry lut[k] from LDS (one ds_read_b32 on the LDS pipe instead of a packed fma and
+// a quarter-rate v_exp_f32 on the VALU port; the factor is then the exact table value).
+#ifndef NB_GRID_FACTOR_LUT
+#define NB_GRID_FACTOR_LUT 0
+#endif
+// General-mass grid kernel, 2-D, R = 4: 0 = scalar sweep (round 2), 1 = packed sweep over the whole source tile (37 VGPRs
+// spilled: measured slower, 1.17 vs 1.06 ms per INT8 step at N = 65 536), 2 = packed sweep over the source tile in two
+// halves (116 VGPRs, no spill: 1.04 ms) -- the default.  Bins identical in all three (tests/test_gpu_bins.py).
+#ifndef NB_GRID_GENERAL_PACKED
+#define NB_GRID_GENERAL_PACKED 2
+#endif
 
 #include <hip/hip_ext.h>
 
@@ -336,8 +348,15 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                         } else {
                             if (EST == GRID_FAST_CLAMP)
                                 kf = f2{__builtin_amdgcn_fmed3f(kf.x, -ga.kcf, 1e30f), __builtin_amdgcn_fmed3f(kf.y, -ga.kcf, 1e30f)};
+#if NB_GRID_FACTOR_LUT
+                            // (padding pairs: the estimate of r2 ~ 1e36 lies far above the table -- clamp to the extra
+                            // zero-weight entry lut[levels])
+                            const int i0 = min((int)(kf.x + ga.kcf), ga.lmax_bin), i1 = min((int)(kf.y + ga.kcf), ga.lmax_bin);
+                            w = f2{ga.lut[i0], ga.lut[i1]};
+#else
                             const f2 th = __builtin_elementwise_fma(kf, f2{ga.c1, ga.c1}, c0c2);
                             w = f2{__builtin_amdgcn_exp2f(th.x), __builtin_amdgcn_exp2f(th.y)};
+#endif
                             if constexpr (BINS) {
                                 kbx = (int)__builtin_fminf(kf.x + ga.kcf, 1e6f);
                                 kby = (int)__builtin_fminf(kf.y + ga.kcf, 1e6f);
@@ -354,6 +373,10 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
                         const int k0 = grid_bin_lookup(ga.thr, r2.x, ga.lp), k1 = grid_bin_lookup(ga.thr, r2.y, ga.lp);
                         w.x = ga.lut[k0];
                         w.y = ga.lut[k1];
+                        if (UNIFORM) {      // the search stops at the last real bin when the table is full: padding particles weigh 0
+                            w.x = (r2.x >= 1e35f) ? 0.0f : w.x;
+                            w.y = (r2.y >= 1e35f) ? 0.0f : w.y;
+                        }
                         if constexpr (BINS) { kbx = k0; kby = k1; }
                     }
                     if constexpr (BINS) {
@@ -429,11 +452,13 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
 template <typename T, int D, int R, bool UNIFORM, int HOOK, int LPC = NB_LUT_MIN, bool BINS = false>
 __global__ void __launch_bounds__(NB_BLOCK, BINS ? 2 : ((HOOK == HOOK_GRID && LPC > NB_LUT_MIN) ? 3 : 4))
 force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work, double *__restrict__ rowslab,
-                 T *__restrict__ colslab, int np, T eps2, const GridTables *__restrict__ tab, float gfac, int gate,
+                 T *__restrict__ colslab, int np, T eps2, const GridTables *__restrict__ tab, float gfac, float g_newton,
                  unsigned long long *__restrict__ bin_out, int bin_n)
 {
     constexpr int B = 64 * R;
-    constexpr int RJ = sym_rj(D, R);            // source slots per sweep
+    constexpr bool F32_ = std::is_same_v<T, float>;
+    // source slots per sweep; the packed general-mass grid kernel (A/B builds) also sweeps the source tile in two halves
+    constexpr int RJ = (NB_GRID_GENERAL_PACKED == 2 && F32_ && HOOK == HOOK_GRID && !UNIFORM && R == 4 && D == 2) ? 2 : sym_rj(D, R);
     constexpr int W = NB_BLOCK / 64;
     constexpr bool F32 = std::is_same_v<T, float>;
     __shared__ T s_aj[W][RJ][D][64];
@@ -454,10 +479,9 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
     int mass_exp = 0;
     if (HOOK == HOOK_GRID) {
         const int levels = tab->levels;
-        // uniform-mass grid kernel (gate 1) and its general-mass stand-in (gate 2) are launched as a
-        // pair; the tables decide on the device which of the two does the work
-        const int ok = tab->uniform_ok;
-        if ((gate == 1 && !ok) || (gate == 2 && ok)) return;
+        // (round 2 launched the uniform-mass grid kernel and a general-mass twin as a pair and let the tables decide on
+        // the device which of the two worked; the uniform kernel now serves every state of the tables itself --
+        // table-free, estimate + threshold, binary search, degenerate pass-through -- so there is ONE launch)
         // table-free pairs produce factors scaled by 2^-tm (GridTables): the table copies are scaled alike
         // (exact: a power of two) and the power of two goes back in with the common mass
         fast = tab->fast_ok != 0;
@@ -481,18 +505,28 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
         ga.c0c = tab->c0c;
         ga.kcf = (float)tab->kc;
         gscale = ldexpf(gfac, tm);
+        if (UNIFORM) ga.gfac = g_newton;      // degenerate pass-through evaluates (1 / q^1.5) * G itself; the common mass follows
         __syncthreads();
     }
 
     T xi[R][D], gi[R];
-    double ai_sum[R][D];      // fp64 running sums over the whole chunk (fp32: folded per tile)
+    // fp64 running sums over the whole chunk (fp32: folded per tile).  The packed uniform-mass grid kernel keeps them
+    // in LDS instead of 8 (12 in 3-D) register pairs: they are touched once per 64-step sweep, and with them in
+    // registers the table-free sweep does not fit 128 VGPRs (round 2: 25-27 VGPRs spilled to scratch).
+    constexpr bool ROW_LDS = F32 && HOOK == HOOK_GRID && R == 4 && LPC == NB_LUT_MIN;
+    __shared__ double s_row[ROW_LDS ? W : 1][ROW_LDS ? R * D : 1][ROW_LDS ? 64 : 1];
+    double ai_sum[ROW_LDS ? 1 : R][ROW_LDS ? 1 : D];
+    auto row_ref = [&](int r, int k) -> double & {
+        if constexpr (ROW_LDS) return s_row[wave][r * D + k][lane];
+        else return ai_sum[r][k];
+    };
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int p = I * B + r * 64 + lane;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             xi[r][k] = packed[(size_t)k * np + p];
-            ai_sum[r][k] = 0.0;
+            row_ref(r, k) = 0.0;
         }
         gi[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
         if constexpr (F32 && HOOK == HOOK_GRID && !UNIFORM) gi[r] = ldexpf(gi[r], mass_exp);
@@ -524,9 +558,8 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
             const bool diag = (J == I);
             // fp32 modes: source slots (2h, 2h+1) packed in float2 halves (sweep_pk).  The general-mass grid kernel
             // keeps the scalar loop (its packed form needs more than 128 VGPRs: measured 1.50 vs 1.24 ms per launch
-            // at N = 65536 with the spills inside the pair loop); the uniform-mass one always has a usable estimate
-            // (GridTables::uniform_ok gates it).
-            constexpr bool use_packed = F32 && (RJ % 2 == 0) && (HOOK != HOOK_GRID || UNIFORM);
+            // at N = 65536 with the spills inside the pair loop).
+            constexpr bool use_packed = F32 && (RJ % 2 == 0) && (HOOK != HOOK_GRID || UNIFORM || (NB_GRID_GENERAL_PACKED && D == 2 && R == 4));
             if constexpr (use_packed) {
                 f2 xj2[RJ / 2][D], gj2[RJ / 2], aj2[RJ / 2][D], ai2[R][D];
 #pragma unroll
@@ -552,8 +585,12 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                 if (HOOK == HOOK_GRID && fast) {
                     if (eps2 < 0.01f) NB_SWEEP_PK(GRID_FAST_CLAMP);
                     else NB_SWEEP_PK(GRID_FAST);
+                } else if (HOOK == HOOK_GRID && degenerate) {
+                    NB_SWEEP_PK(GRID_DEGENERATE);
+                } else if (HOOK == HOOK_GRID && use_est) {
+                    NB_SWEEP_PK(GRID_EST);
                 } else if (HOOK == HOOK_GRID) {
-                    NB_SWEEP_PK(GRID_EST);           // only reached with a usable estimate
+                    NB_SWEEP_PK(GRID_SEARCH);        // very narrow grids / NaN bounds: no usable estimate
                 } else {
                     NB_SWEEP_PK(0);
                 }
@@ -565,7 +602,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int k = 0; k < D; ++k) ai_sum[r][k] += (double)(ai2[r][k].x + ai2[r][k].y);
+                    for (int k = 0; k < D; ++k) row_ref(r, k) += (double)(ai2[r][k].x + ai2[r][k].y);
             } else {
                 T xj[RJ][D], gj[RJ], ai[R][D];
 #pragma unroll
@@ -579,7 +616,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int k = 0; k < D; ++k) ai[r][k] = F32 ? (T)0 : (T)ai_sum[r][k];
+                    for (int k = 0; k < D; ++k) ai[r][k] = F32 ? (T)0 : (T)row_ref(r, k);
 #define NB_SWEEP(EE)                                                                                                  \
     do {                                                                                                                 \
         if (diag) sweep<T, D, R, RJ, true, UNIFORM, HOOK, EE, BINS>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count, bd);     \
@@ -594,7 +631,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int k = 0; k < D; ++k) ai_sum[r][k] = F32 ? ai_sum[r][k] + (double)ai[r][k] : (double)ai[r][k];
+                    for (int k = 0; k < D; ++k) row_ref(r, k) = F32 ? row_ref(r, k) + (double)ai[r][k] : (double)ai[r][k];
             }
         }
         if constexpr (BINS) {
@@ -649,7 +686,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
 #pragma unroll
         for (int k = 0; k < D; ++k)
             rowslab[((size_t)slot * D + k) * B + r * 64 + lane] =
-                (UNIFORM && HOOK == HOOK_GRID) ? ai_sum[r][k] * (double)gscale : ai_sum[r][k];
+                (UNIFORM && HOOK == HOOK_GRID) ? row_ref(r, k) * (double)gscale : row_ref(r, k);
 }
 
 template <typename T, int D, int R, int HOOK, int LPC, bool BINS = false>
@@ -657,19 +694,16 @@ hipError_t launch_sym_lpc(const T *packed, const SymWork *work, int nwork, doubl
                           int uniform, T eps2, const GridTables *tab, float gfac, hipStream_t st, NbKernelEvents ev,
                           float mass_value, unsigned long long *bin_out = nullptr, int bin_n = 0)
 {
-    if (uniform && HOOK == HOOK_GRID) {
-        // uniform-mass grid kernel, valid only while the tables say so (GridTables::uniform_ok, known on the
-        // device only): launch it together with the general kernel, exactly one of the two does the work
+    // g_newton: G for the uniform-mass grid kernel (its gfac carries the common mass; its tables carry G already)
+    if (uniform && HOOK == HOOK_GRID)
         hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK, LPC, BINS>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
-                              nullptr, 0, packed, work, rowslab, colslab, np, eps2, tab, mass_value, 1, bin_out, bin_n);
-        hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK, LPC, BINS>), dim3(nwork), dim3(NB_BLOCK), 0, st, nullptr,
-                              ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 2, bin_out, bin_n);
-    } else if (uniform)
+                              ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, mass_value, gfac, bin_out, bin_n);
+    else if (uniform)
         hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, true, HOOK, LPC, BINS>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
-                              ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 0, bin_out, bin_n);
+                              ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 0.0f, bin_out, bin_n);
     else
         hipExtLaunchKernelGGL((force_sym_kernel<T, D, R, false, HOOK, LPC, BINS>), dim3(nwork), dim3(NB_BLOCK), 0, st, ev.start,
-                              ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 0, bin_out, bin_n);
+                              ev.stop, 0, packed, work, rowslab, colslab, np, eps2, tab, gfac, 0.0f, bin_out, bin_n);
     return hipGetLastError();
 }
 

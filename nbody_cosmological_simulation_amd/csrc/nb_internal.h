@@ -32,8 +32,8 @@ struct GridTables {
     int levels;
     unsigned int r2max_bits; // atomicMax target (positive floats order as unsigned ints)
     unsigned int blocks_done; // grid_tables_kernel: arrival counter of its blocks (the last one finalises)
-    int uniform_ok;          // 1: the uniform-mass grid kernel may run (estimate usable, r2max far below the
-                             //    padding distance, so "r2 >= 1e35" identifies padding particles)
+    int uniform_ok;          // (round 2: gate of the uniform / general pair of launches; informational since round 3 -- the
+                             //  uniform-mass grid kernel serves every state of the tables itself)
     // Table-free pair path.  A pair whose bin estimate sits further than `sure_lim` from
     // a bin edge has bin rint(estimate) for certain; its force factor follows from the bin index alone:
     // log2(lut[k]) is affine in k, so lut[k] * 2^-tm = v_exp_f32((k - kc) * c1 + c0c), with kc the middle bin and
@@ -68,6 +68,20 @@ struct PruneState {
     unsigned long long lb[2]; // (r2 bits << 32 | index): farthest partner of `far`, then of that partner
     int count;                // candidates kept
     int nan_flag;             // a NaN coordinate was seen -> r2max is NaN
+    // ---- tracked search (round 3): after a seeding evaluation every further one starts from its predecessor's result.
+    // The farthest pair of the last evaluation, re-evaluated at the new positions, is the lower bound the two hops
+    // used to find; the centre stays where the seeding evaluation put it (any fixed point serves the bound
+    // dist(a, b) <= rho_a + rho_max), and the bound on rho_max is the last measured maximum plus a margin (twice its last
+    // growth + 1e-4 of it: a RELATIVE margin alone would swallow the whole galaxy once a lone escaper is far out) that
+    // the filter pass itself checks (a violated margin makes the scan fall back to all pairs: exact either way).
+    int seeded;               // c / rho_m / pair are valid
+    float c[3];               // centre of the candidate test
+    float rho_m;              // assumed upper bound of every particle's distance from c (checked against rho_cur)
+    float rho_prev;           // the measured maximum of the evaluation before (0: none yet) -- its growth sets the margin
+    int pair_i, pair_j;       // a far pair of the last evaluation
+    unsigned int rho_cur;     // filter pass: bits of the largest distance from c seen (atomicMax; distances are >= 0)
+    unsigned int scan_done;   // scan: arrival counter of its workgroups (the last one finalises)
+    unsigned long long best_i, best_j;   // scan: (r2 bits << 32 | particle index) maxima over all scanned pairs
 };
 
 struct ForceGeom {
@@ -160,6 +174,12 @@ hipError_t nb_launch_r2max(const float *pos, const ForceGeom &g, int dim, float 
 // O(N) + (candidates)^2 work, no collective); cand: n*dim floats, rho: n floats, st: PruneState
 hipError_t nb_launch_r2max_pruned(const float *pos, int n, int dim, float eps2, float *cand, float *rho,
                                   PruneState *ps, GridTables *tab, hipStream_t st);
+// tracked search, two launches: filter (O(N): candidates of the maximal pair, compacted with their indices) and scan
+// (exact max over candidate pairs; its last workgroup finalises, prepares the next evaluation's search and -- for
+// levels <= NB_LUT_MIN -- builds the tables as well: no grid_tables launch).  Needs a seeded *ps (nb_launch_r2max_pruned
+// followed by nb_launch_grid_tables seeds it).
+hipError_t nb_launch_r2max_tracked(const float *pos, int n, int dim, float eps2, float *cand, int *cand_idx, PruneState *ps,
+                                   GridTables *tab, int levels, float G, float min_val, int allow_fast, hipStream_t st);
 hipError_t nb_launch_grid_tables(GridTables *tab, int levels, float G, float eps2, float min_val,
                                  PruneState *ps /* reset after use; may be null */, hipStream_t st, int allow_fast = 1);
 hipError_t nb_launch_d2bins(const float *pos, int n, int dim, float eps2, const GridTables *tab,

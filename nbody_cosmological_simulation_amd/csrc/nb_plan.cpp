@@ -25,6 +25,7 @@ NbKnobs nb_read_knobs()
     if (k.tail_pieces != 2 && k.tail_pieces != 4 && k.tail_pieces != 8 && k.tail_pieces != 16) k.tail_pieces = 0;
     k.r_onesided = env_int("NB_R", 0);
     k.no_prune = getenv("NB_NO_PRUNE") != nullptr;
+    k.no_track = env_int("NB_NO_TRACK", 0) != 0;
     k.no_pe_sym = getenv("NB_NO_PE_SYM") != nullptr;
     k.no_uniform = getenv("NB_NO_UNIFORM") != nullptr;
     k.no_smalln = getenv("NB_NO_SMALLN") != nullptr;

@@ -19,6 +19,7 @@ struct NbKnobs {
     int tail_pieces = 0;   // NB_SYM_TAIL: pieces per sweep of the tail-smoothed super-rows (4 or 8); 0 = auto
     int r_onesided = 0;    // NB_R: targets per thread of the one-sided fp64 kernel
     bool no_prune = false;   // NB_NO_PRUNE: all-pairs max-r2 scan at any N
+    bool no_track = false;   // NB_NO_TRACK: every grid evaluation searches its farthest pair from scratch (A/B of round 3's tracked search)
     bool no_pe_sym = false;  // NB_NO_PE_SYM: one-sided potential-energy kernel
     bool no_uniform = false; // NB_NO_UNIFORM: general-mass kernels even for equal masses
     bool no_smalln = false;  // NB_NO_SMALLN: never use the single-launch small-N step

@@ -120,7 +120,9 @@ struct nb_sim {
     double *scalars = nullptr;           // device: [0,1] force min/max, [2] ke, [3] pe
     int16_t *fbins = nullptr;            // n*dim, INT8/INT4 only
     float *prune_cand = nullptr, *prune_rho = nullptr;   // grid modes: pruned max-r2 search
+    int *prune_idx = nullptr;            // ... particle indices of the compacted candidates (tracked search)
     PruneState *prune_state = nullptr;
+    bool prune_seeded = false;           // the last evaluation left a far pair / centre / rho bound for a tracked search
     bool mass_uniform = false;           // all masses equal (checked on the device at upload)
     double mass_value = 0.0;
     const char *last_kernel = "none";

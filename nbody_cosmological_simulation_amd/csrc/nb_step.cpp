@@ -15,7 +15,12 @@ namespace nbhost {
 struct NbTuning {
     int onesided_r1_max_n = 8192;       // one-sided fp64 kernel: one target per thread up to here (parallelism-bound)
     int onesided_target_wgs = 1024;     // ... and enough source chunks for >= 4 workgroups per CU
-    int prune_min_n = 8192;             // grid modes: pruned max-r2 search above, all-pairs scan at or below
+    int prune_min_n = 8192;             // grid modes, first evaluation: pruned max-r2 search above, all-pairs scan at or below
+    int track_min_n = 3072;             // grid modes: above, every evaluation after the first TRACKS the farthest pair of its
+                                        // predecessor (two launches incl. the tables; the seed then always prunes).  On the
+                                        // one-launch small-system path the all-pairs pass costs the same (measured INT8 / CUSTOM
+                                        // N = 3000: 31.3 / 27.1 vs 31.0 / 26.7 us per step: the table construction by a single
+                                        // workgroup is what is left there, not the search)
     int red_mm_max_blocks = 512;        // INT8 / INT4: the reduction also hands out force min / max partials up to
                                         // N = 32 768 (beyond, every finish workgroup would fold thousands of them)
     int small_max_f64 = 4096;           // one-launch step: fp64 4.9 / 7.9 / 11.4 / 16.9 us per step at N = 1024 ... 4096
@@ -225,7 +230,18 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready, bool *defer_kick, boo
             // tab->r2max_bits is 0 here: zeroed at creation, put back by grid_tables_kernel after each use.
             // Small systems scan all pairs in one launch; the pruned search (six launches, O(N) + candidates^2)
             // pays off above that.
-            const bool prune = !s->knobs.no_prune && c.n > g_tune.prune_min_n;
+            // Tracked search: the farthest pair of the previous evaluation gives this one's lower bound, so two launches
+            // (filter, scan + tables) replace six + one (round 3; exact either way, nb_force.hip).  Single GPU or every rank
+            // redundantly; not for comm-less shards, whose first evaluation is their only one.
+            const bool track = !s->knobs.no_prune && !s->knobs.no_track && c.n > g_tune.track_min_n && !(no_comm && c.nranks > 1);
+            const bool prune = !s->knobs.no_prune && (c.n > g_tune.prune_min_n || track);
+            if (track && s->prune_seeded) {
+                HIPCHK(nb_launch_r2max_tracked((const float *)s->pos, c.n, c.dim, eps2, s->prune_cand, s->prune_idx, s->prune_state,
+                                               s->tab, L, (float)c.G, 0.01f, s->knobs.no_grid_fast ? 0 : 1, s->stream));
+                if (L > NB_LUT_MIN)      // multi-block tables: the scan left the maximum in tab->r2max_bits
+                    HIPCHK(nb_launch_grid_tables(s->tab, L, (float)c.G, eps2, 0.01f, nullptr, s->stream,
+                                                 s->knobs.no_grid_fast ? 0 : 1));
+            } else {
             if (prune) {
                 // every rank finds the global maximum itself: O(N) + (outer candidates)^2, no collective
                 HIPCHK(nb_launch_r2max_pruned((const float *)s->pos, c.n, c.dim, eps2, s->prune_cand, s->prune_rho,
@@ -244,6 +260,8 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready, bool *defer_kick, boo
             }
             HIPCHK(nb_launch_grid_tables(s->tab, L, (float)c.G, eps2, 0.01f, prune ? s->prune_state : nullptr,
                                          s->stream, s->knobs.no_grid_fast ? 0 : 1));
+            s->prune_seeded = prune;     // grid_tables_kernel seeded the tracked search from the pruned one's far pair
+            }
         }
         used_sym = s->sym.enabled && pa == NB_F32;
         if (used_sym) {
@@ -413,7 +431,11 @@ int small_grid_tables(nb_sim *s)
 {
     const nb_config &c = s->cfg;
     const float eps2f = (float)c.softening_sq;
-    if (mode_levels(c) <= NB_LUT_MIN && c.n <= g_tune.small_fuse_tables_max_n && !s->knobs.no_small_fuse) {
+    if (s->prune_seeded && !s->knobs.no_prune && !s->knobs.no_track && c.n > g_tune.track_min_n) {
+        // the first evaluation (tiled path) seeded the tracked search: filter + scan (+ tables) instead of an all-pairs pass
+        HIPCHK(nb_launch_r2max_tracked((const float *)s->pos, c.n, c.dim, eps2f, s->prune_cand, s->prune_idx, s->prune_state,
+                                       s->tab, mode_levels(c), (float)c.G, 0.01f, s->knobs.no_grid_fast ? 0 : 1, s->stream));
+    } else if (mode_levels(c) <= NB_LUT_MIN && c.n <= g_tune.small_fuse_tables_max_n && !s->knobs.no_small_fuse) {
         HIPCHK(nb_launch_r2max_tables((const float *)s->pos, s->geom, c.dim, eps2f, s->tab, mode_levels(c), (float)c.G, 0.01f,
                                       s->knobs.no_grid_fast ? 0 : 1, s->stream));
     } else {
@@ -609,7 +631,7 @@ int bin_sums_eval(nb_sim *s, int which, int64_t *sum_k, int64_t *sum_kw, double 
     hipError_t e = hipMemcpyAsync(host.data(), s->bin_out, words * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ht, s->tab, sizeof(GridTables), hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-    const int fast_ok = ht->fast_ok, uniform_ok = ht->uniform_ok, degenerate = ht->degenerate;
+    const int fast_ok = ht->fast_ok, degenerate = ht->degenerate;
     delete ht;
     HIPCHK(e);
     if (degenerate) return fail(NB_ERR_UNSUPPORTED, "quant-bin read-out: degenerate grid (lmax - lmin < 1e-10): values pass through, no bins");
@@ -618,7 +640,7 @@ int bin_sums_eval(nb_sim *s, int which, int64_t *sum_k, int64_t *sum_kw, double 
         info[0] = path;                   // 1 pair-symmetric tiles, 2 one-sided tiles, 3 one-launch small-system kernel
         info[1] = shape;                  // targets per lane (1) / lanes per target (3)
         // the uniform-mass packed kernel did the work (pair-symmetric path; the same rule force_eval applies)
-        info[2] = (path == 1 && s->mass_uniform && s->sym.r != 2 && uniform_ok) ? 1 : 0;
+        info[2] = (path == 1 && s->mass_uniform && s->sym.r != 2) ? 1 : 0;
         info[3] = fast_ok;                // the tables enabled the table-free pair path
         info[4] = (double)host[2 * (size_t)c.n];        // pair evaluations binned by the table-free estimate alone
         info[5] = (double)host[2 * (size_t)c.n + 1];    // pair evaluations binned through a threshold table

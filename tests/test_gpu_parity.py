@@ -1250,6 +1250,85 @@ def test_grid_mode_trajectories_vs_reference_within_its_own_noise(nb, case, mode
     assert abs(sim.get_total_energy() - e_ref) <= max(2 * float(noise[f"{tag}/ulp100/energy_relerr"]), 2e-6) * abs(e_ref)
 
 
+def _exact_r2max_f32(pos, eps2):
+    """max over all pairs of the reference's fp32 r2 = ((dx*dx + dy*dy) [+ dz*dz]) + eps2, one rounding per op (numpy fp32)."""
+    pos = np.ascontiguousarray(pos, np.float32)
+    e = np.float32(eps2)
+    best = np.float32(0)
+    for i0 in range(0, pos.shape[0], 512):
+        d = pos[None, :, :] - pos[i0:i0 + 512, None, :]
+        sq = d * d
+        r2 = sq[..., 0] + sq[..., 1]
+        if pos.shape[1] == 3:
+            r2 = r2 + sq[..., 2]
+        best = max(best, (r2 + e).max())
+    return np.float32(best)
+
+
+@pytest.mark.parametrize("mode", ["int4_sim", "custom"])
+@pytest.mark.parametrize("n,d", [(3000, 2), (2500, 3), (9000, 2), (30000, 2)])
+def test_tracked_max_r2_search_is_exact_over_steps(nb, monkeypatch, n, d, mode):
+    """Round 3: after its first evaluation a grid-mode simulation TRACKS the farthest pair (filter + scan, two launches,
+    tables built by the scan's last workgroup) instead of searching it from scratch.  The maximum must stay the exact
+    fp32 maximum over all pairs at every step -- also when a star outruns the margin of the candidate test (the scan
+    then falls back to all pairs), on the one-launch small-system path (N = 3000, 2500) and on the tiled paths -- and
+    the trajectory must be bit-identical to a run that searches from scratch every time (NB_NO_TRACK)."""
+    rng = np.random.default_rng(n + d)
+    pos = (rng.standard_normal((n, d)) * 4).astype(np.float32)
+    vel = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
+    pos[7] = 0.0
+    pos[7, 0] = 25.0                           # an escaper at the rim: 0.6 per step outwards, far beyond the 0.5 % margin
+    vel[7] = 0.0                               # on rho_max -- every step's filter sees its bound violated
+    vel[7, 0] = 60.0
+    mass = np.ones(n, np.float32)
+    eps2 = np.float32(0.1 * 0.1)
+
+    def run(track):
+        if track:
+            monkeypatch.delenv("NB_NO_TRACK", raising=False)
+        else:
+            monkeypatch.setenv("NB_NO_TRACK", "1")
+        sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode(mode))
+        got = []
+        for _ in range(6):
+            sim.run(1)
+            dbg = sim.quant_debug()
+            got.append((np.float32(dbg["r2max"]), np.float32(dbg["lmax"]), sim.positions.numpy().copy()))
+        return got
+
+    tracked, scratch = run(True), run(False)
+    for step, ((r_t, l_t, x_t), (r_s, l_s, x_s)) in enumerate(zip(tracked, scratch)):
+        want = _exact_r2max_f32(x_t, eps2)
+        assert r_t == want, (step, r_t, want)
+        assert r_s == want and l_t == l_s
+        assert np.array_equal(x_t, x_s), f"step {step}: the tracked search changed the trajectory"
+    # the escaper did become a member of the farthest pair
+    assert tracked[-1][0] > tracked[0][0]
+
+
+def test_tracked_max_r2_search_survives_nan_and_new_positions(nb):
+    """A NaN coordinate poisons the grid exactly like the from-scratch search (torch's max() is NaN); writing new
+    positions re-seeds the search."""
+    rng = np.random.default_rng(0)
+    n = 5000
+    pos = (rng.standard_normal((n, 2)) * 4).astype(np.float32)
+    sim = nb.GalaxySimulation(T(pos), torch.zeros(n, 2), torch.ones(n), precision_mode=nb.PrecisionMode.CUSTOM)
+    sim.run(2)
+    x = sim.positions.numpy().copy()
+    assert np.float32(sim.quant_debug()["r2max"]) == _exact_r2max_f32(x, np.float32(0.01))
+    far = x * np.float32(3.0)                   # a different, three times larger system: the old far pair / bound are stale
+    sim.positions = T(far)
+    sim.run(1)
+    assert np.float32(sim.quant_debug()["r2max"]) == _exact_r2max_f32(sim.positions.numpy(), np.float32(0.01))
+    bad = sim.positions.numpy().copy()
+    sim.run(1)                                  # tracked again ...
+    bad = sim.positions.numpy().copy()
+    bad[11, 1] = np.nan
+    sim.positions = T(bad)
+    sim.run(2)                                  # ... seeded with a NaN, then tracked with a NaN
+    assert np.isnan(sim.quant_debug()["r2max"]) and torch.isnan(sim.accelerations).all()
+
+
 @pytest.mark.parametrize("L,sym", [(512, 0), (1000, 1), (4096, 0), (4096, 1)])
 def test_custom_levels_above_256_bins(nb, monkeypatch, L, sym):
     """sensitivity_test.py sweeps 512 / 1024 / 4096 levels: the fused path serves up to 4096 (tables sized per

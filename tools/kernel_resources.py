@@ -12,7 +12,7 @@ def main():
     src = sys.argv[1]
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
-           "-I/opt/rocm/include", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+           "-I/opt/rocm/include", *sys.argv[3:], "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
     txt = subprocess.run(cmd, capture_output=True, text=True).stderr
     for b in txt.split("Function Name: ")[1:]:
         name = b.split("\n")[0].strip().split()[0]
