@@ -158,6 +158,116 @@ def cpu_baseline(pos, vel, mass, target_s, ref_sizes, gpu_drift):
     }
 
 
+def collective_report(sim, runtime, nb, dist, world, n, pos, vel, mass, mode, dev):
+    """What the per-step collective is and costs on THIS node, for every run with a communicator -- and never at the
+    price of the bench line: every probe is wrapped, a failing one is reported by name.  Collective (every rank)."""
+    import ctypes
+    from nbody_cosmological_simulation_amd import _native, checkpoint
+    rep = {"force_vector_bytes": n * pos.shape[1] * (8 if mode == nb.PrecisionMode.FLOAT64 else 4)}
+
+    def probe(key, fn):
+        try:
+            rep[key] = fn()
+        except Exception as exc:            # noqa: BLE001 -- the line must be printed whatever a probe does
+            rep[key] = None
+            rep.setdefault("probe_errors", {})[key] = repr(exc)[:300]
+
+    def comm_info():
+        info = (ctypes.c_int32 * 8)()
+        _native.check(_native.lib().nb_comm_info(info))
+        return {"ranks": info[0], "rank": info[1], "device": info[2], "direct_only": bool(info[3]),
+                "rccl_nranks": info[4], "direct_state": {0: "none", 1: "attached", 2: "enabled"}[info[5]],
+                "direct_nranks": info[6]}
+    probe("communicator", comm_info)                     # rccl_nranks = ncclCommCount() of the communicator in use
+    probe("carrier", runtime.allreduce_label)            # which path carries the force vectors of `sim`
+    probe("direct_setup", lambda: runtime._p2p_log.get("state"))
+    # back-to-back all-reduces of the force vector on zeroed scratch, per carrier (None: carrier not available)
+    probe("rccl_us_per_allreduce", lambda: sim.allreduce_time("rccl"))
+    probe("direct_us_per_allreduce", lambda: sim.allreduce_time("direct"))
+
+    def identical():
+        hashes = [checkpoint.state_hash(sim)]
+        if world > 1:
+            hashes = [None] * world
+            dist.all_gather_object(hashes, checkpoint.state_hash(sim))
+        return len(set(hashes)) == 1
+    probe("ranks_hold_identical_state", identical)       # the invariant of the replicated integration
+    # the two carriers against each other: five steps from the same initial conditions through the direct all-reduce
+    # and through RCCL (NB_NO_P2P is read when a simulation is created) must agree to rounding (their summation orders
+    # differ) -- a stale or torn read on the direct path would show here
+    if rep.get("carrier") and "direct" in rep["carrier"] and rep.get("rccl_us_per_allreduce") is not None:
+        def five_steps(rccl_only):
+            if rccl_only:
+                os.environ["NB_NO_P2P"] = "1"
+            try:
+                s2 = nb.GalaxySimulation(pos.to(dev), vel.to(dev), mass.to(dev), precision_mode=mode, G=0.001,
+                                         softening=0.1, dt=0.01, device=dev)
+            finally:
+                os.environ.pop("NB_NO_P2P", None)
+            s2.run(5)
+            x = s2.positions.double().cpu()
+            s2.close()
+            return x
+
+        def compare():
+            xa, xb = five_steps(False), five_steps(True)
+            return float((xa - xb).abs().max() / xb.abs().max())
+        probe("direct_vs_rccl_relerr_5_steps", compare)
+    return rep
+
+
+def gpu_rows(nb, galaxy, dev, sizes):
+    """The engine at the sizes the CPU rows of cpu_baseline.reference_formulation_torch_cpu are taken at (the reference
+    harness's own range, density_limit_test.py:69-203): fp64 and fp32, omega_point_test.py:305-319 idiom (10 warm-up
+    steps, perf_counter around >= 10 steps -- 200 here, the steps are microseconds)."""
+    rows = []
+    for nr in sizes:
+        pos, vel, mass = galaxy.create_disk_galaxy(nr, seed=42, device="cpu")
+        for mode in ("float64", "float32"):
+            sim = nb.GalaxySimulation(pos.to(dev), vel.to(dev), mass.to(dev), precision_mode=nb.get_mode_from_string(mode),
+                                      G=0.001, softening=0.1, dt=0.01, device=dev)
+            sim.run(10)
+            t = time.perf_counter()
+            while time.perf_counter() - t < 0.05:        # past the clock ramp
+                sim.run(50)
+                sim.synchronize()
+            steps = 200
+            t0 = time.perf_counter()
+            sim.run(steps)
+            sim.synchronize()
+            dt = time.perf_counter() - t0
+            rows.append({"n": nr, "mode": mode, "ms_per_step": dt / steps * 1e3, "particle_steps_per_s": nr * steps / dt,
+                         "pair_interactions_per_s": float(nr) * nr * steps / dt, "kernel": sim.force_kernel_name()})
+            sim.close()
+    return rows
+
+
+def mode_rows(nb, pos, vel, mass, dev):
+    """BASELINE config 3 (N = 65 536 precision sweep): every precision mode's force launch (HIP events on the dispatch)
+    and whole step, against the peak of the type it computes in."""
+    rows = []
+    n = pos.shape[0]
+    for mode in nb.PrecisionMode:
+        sim = nb.GalaxySimulation(pos.to(dev), vel.to(dev), mass.to(dev), precision_mode=mode, G=0.001, softening=0.1,
+                                  dt=0.01, device=dev, profile=True)
+        sim.run(30)
+        sim.synchronize()
+        sim.kernel_time()
+        steps = 60
+        t0 = time.perf_counter()
+        sim.run(steps)
+        sim.synchronize()
+        dt = time.perf_counter() - t0
+        ms, launches = sim.kernel_time()
+        peak = FP64_VECTOR_PEAK_TFLOPS if mode == nb.PrecisionMode.FLOAT64 else FP32_VECTOR_PEAK_TFLOPS
+        avg = ms / max(launches, 1)
+        tf = FLOP_PER_PAIR_2D * float(n) * n / (avg * 1e-3) / 1e12
+        rows.append({"mode": mode.value, "ms_per_force_launch": avg, "launches": launches, "ms_per_step": dt / steps * 1e3,
+                     "tflops": tf, "peak": peak, "frac": tf / peak, "kernel": sim.force_kernel_name()})
+        sim.close()
+    return rows
+
+
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the COMMITTED rocprofv3 PMC summary (collected in separate
     --pmc passes as the MI355X guide prescribes) with its provenance, or (None, why) when not profiled."""
@@ -256,36 +366,7 @@ def main():
     e1 = sim.get_total_energy()
     collective = None
     if world > 1 or runtime.force_comm():
-        # what the per-step collective costs on THIS node (both carriers, back-to-back calls on zeroed scratch),
-        # and the invariant of the replicated integration: every rank holds the same bits
-        from nbody_cosmological_simulation_amd import checkpoint
-        collective = {"force_vector_bytes": n * pos.shape[1] * (8 if mode == nb.PrecisionMode.FLOAT64 else 4),
-                      "carrier": runtime.allreduce_label(),
-                      "rccl_us_per_allreduce": sim.allreduce_time("rccl"),
-                      "direct_us_per_allreduce": sim.allreduce_time("direct")}
-        hashes = [checkpoint.state_hash(sim)]
-        if world > 1:
-            hashes = [None] * world
-            dist.all_gather_object(hashes, checkpoint.state_hash(sim))
-        collective["ranks_hold_identical_state"] = len(set(hashes)) == 1
-        # the two carriers against each other on THIS node: five steps from the same initial conditions through the
-        # direct all-reduce and through RCCL (NB_NO_P2P is read when a simulation is created) must agree to
-        # rounding (their summation orders differ) -- a stale or torn read on the direct path would show here
-        if "direct" in collective["carrier"] and collective["rccl_us_per_allreduce"] is not None:
-            def five_steps(rccl_only):
-                if rccl_only:
-                    os.environ["NB_NO_P2P"] = "1"
-                try:
-                    s2 = nb.GalaxySimulation(pos.to(dev), vel.to(dev), mass.to(dev), precision_mode=mode, G=0.001,
-                                             softening=0.1, dt=0.01, device=dev)
-                finally:
-                    os.environ.pop("NB_NO_P2P", None)
-                s2.run(5)
-                x = s2.positions.double().cpu()
-                s2.close()
-                return x
-            xa, xb = five_steps(False), five_steps(True)
-            collective["direct_vs_rccl_relerr_5_steps"] = float((xa - xb).abs().max() / xb.abs().max())
+        collective = collective_report(sim, runtime, nb, dist, world, n, pos, vel, mass, mode, dev)
 
     if rank == 0:
         is64 = mode == nb.PrecisionMode.FLOAT64
@@ -347,6 +428,18 @@ def main():
                 return (eb - ea) / abs(ea)
             sizes = [int(v) for v in args.ref_sizes.split(",") if v.strip()]
             out["cpu_baseline"] = cpu_baseline(pos, vel, mass, args.cpu_seconds, sizes, gpu_drift)
+            # the same sizes on the GPU, beside the CPU rows, and config 3's per-mode numbers
+            try:
+                out["gpu_rows"] = {"what": "this engine at the sizes of cpu_baseline.reference_formulation_torch_cpu.rows: "
+                                           "10 warm-up + 200 timed steps per row, state resident in HBM",
+                                   "rows": gpu_rows(nb, galaxy, dev, sizes)}
+                if n == 65536:
+                    out["modes"] = {"what": "BASELINE config 3: every precision mode at N = 65536 (30 warm-up + 60 timed steps; "
+                                            "force launch by HIP events on the dispatch; frac = 14 N^2 flop / launch / peak of "
+                                            "the compute type)",
+                                    "rows": mode_rows(nb, pos, vel, mass, dev)}
+            except Exception as exc:            # noqa: BLE001 -- context rows never break the bench line
+                out["gpu_rows_error"] = repr(exc)[:300]
         print(json.dumps(out), flush=True)
     sim.close()
     runtime.shutdown()                # the process communicator: collective, every rank, before the process group goes

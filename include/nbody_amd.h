@@ -264,7 +264,9 @@ int nb_comm_allreduce_time(nb_sim *s, int32_t which, int32_t iters, double *us_p
  * the 8-rank geometry): concurrent = 0 runs the ranks' kernels one after the other with pre-satisfied flags, twice;
  * concurrent = 1 uses one stream per rank and the real barriers (as many hardware queues as ranks: up to 4),
  * concurrent = 2 runs all ranks in one dispatch (co-resident by construction, any rank count); both report the time
- * per all-reduce.  *bad = elements that differ from the closed form (+1e6 per rank whose barrier timed out). */
+ * per all-reduce.  concurrent = 3: like 1, but the last rank never launches its all-reduce (a dead peer): the others
+ * must leave their barriers after timeout_s, raise their status word and drain -- the call returns NB_OK with
+ * *bad >= 1e6.  *bad = elements that differ from the closed form (+1e6 per rank whose barrier timed out). */
 int nb_comm_p2p_virtual_test(int32_t device, int32_t nranks, int64_t count, int32_t dtype, int32_t concurrent,
                              int32_t iters, double timeout_s, int32_t *bad, double *us_per_call);
 /* tests: all-reduce `count` host elements (NB_F32 / NB_F64) in place through the direct path (collective) */

@@ -515,7 +515,7 @@ hipError_t nb_p2p_virtual(int nranks, size_t count, int is_f64, int concurrent, 
     const int fb = (int)((units + 255) / 256);
     for (int it = 0; it < iters && e == hipSuccess; ++it) {
         for (int q = 0; q < nranks; ++q) {
-            hipStream_t s = concurrent == 1 ? st[q] : st[0];
+            hipStream_t s = (concurrent == 1 || concurrent == 3) ? st[q] : st[0];
             if (is_f64) hipLaunchKernelGGL(p2p_fill_kernel<true>, dim3(fb), dim3(256), 0, s, (u64 *)(region[q] + P2P_SIG_BYTES), units, q, it);
             else hipLaunchKernelGGL(p2p_fill_kernel<false>, dim3(fb), dim3(256), 0, s, (u64 *)(region[q] + P2P_SIG_BYTES), units, q, it);
         }
@@ -524,11 +524,14 @@ hipError_t nb_p2p_virtual(int nranks, size_t count, int is_f64, int concurrent, 
         if (concurrent == 2) {
             launch_node(st[0]);
         } else {
+            // concurrent = 3: like 1, but the LAST rank never launches its all-reduce -- a dead peer.  The others must
+            // leave their barrier after timeout_s, raise their status word and drain (error-path test).
+            const int launched = concurrent == 3 ? nranks - 1 : nranks;
             for (int pass = 0; pass < (concurrent ? 1 : 2); ++pass)
-                for (int q = 0; q < nranks; ++q) launch(q, concurrent ? st[q] : st[0]);
+                for (int q = 0; q < launched; ++q) launch(q, concurrent ? st[q] : st[0]);
         }
         for (int q = 0; q < nranks; ++q) {
-            hipStream_t s = concurrent == 1 ? st[q] : st[0];
+            hipStream_t s = (concurrent == 1 || concurrent == 3) ? st[q] : st[0];
             int *dbg = debug ? bad + 1 + 4 * q : nullptr;
             if (is_f64) hipLaunchKernelGGL(p2p_check_kernel<true>, dim3(fb), dim3(256), 0, s, (const u64 *)dst[q], units, nranks, it, bad, dbg, dbg_val + q);
             else hipLaunchKernelGGL(p2p_check_kernel<false>, dim3(fb), dim3(256), 0, s, (const u64 *)dst[q], units, nranks, it, bad, dbg, dbg_val + q);

@@ -143,6 +143,14 @@ def attach_direct_allreduce(device: int, world: int, rank: int, capacity_bytes: 
     ok = all(_all_gather(bool(ok), world))
     if ok:
         ok = L.nb_comm_p2p_selftest(rounds, timeout_s) == 0
+        if os.environ.get("NB_TEST_P2P_FAIL_RANK") == str(rank):
+            # test hook: this rank reports a failed self-test -- every rank must then vote the direct path down and
+            # leave the step to RCCL (tests/test_gpu_parity.py::test_direct_allreduce_failure_paths)
+            ok = False
+            mine["err"] = "self-test failure injected on rank %d (NB_TEST_P2P_FAIL_RANK)" % rank
+            everyone = _all_gather(mine, world)
+        elif os.environ.get("NB_TEST_P2P_FAIL_RANK") is not None:
+            everyone = _all_gather(mine, world)
         ok = all(_all_gather(bool(ok), world))
     if not ok:
         errs = [e["err"] for e in everyone if e["err"]] or [N.last_error()]

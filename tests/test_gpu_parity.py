@@ -2099,6 +2099,92 @@ def test_multi_rank_product_path_on_one_gpu(nb, world, variant, tmp_path):
     assert ranks[0]["f64_onesided"]["kernel"].startswith("force_f64")
 
 
+def test_direct_allreduce_dead_peer_drains_within_its_timeout(nb):
+    """The bounded wait of the direct all-reduce kernel, exercised once: two virtual ranks, the second
+    one never launches.  The first must give up after timeout_s, raise its status word and drain -- the call returns
+    (no hang), reports the timed-out rank, and the kernel works normally afterwards."""
+    import ctypes
+    import time
+    from nbody_cosmological_simulation_amd import _native as N
+    L = N.lib()
+    bad, us = ctypes.c_int32(0), ctypes.c_double(0.0)
+    t0 = time.perf_counter()
+    N.check(L.nb_comm_p2p_virtual_test(0, 2, 131072, N.NB_F64, 3, 1, 0.5, ctypes.byref(bad), ctypes.byref(us)))
+    took = time.perf_counter() - t0
+    assert bad.value >= 1000000, bad.value                  # a barrier timed out and said so
+    assert 0.4 < took < 10.0, took                          # ... after the timeout, not never
+    N.check(L.nb_comm_p2p_virtual_test(0, 2, 131072, N.NB_F64, 2, 3, 2.0, ctypes.byref(bad), ctypes.byref(us)))
+    assert bad.value == 0
+
+
+@pytest.mark.parametrize("scenario", ["dead-peer", "vote-no"])
+def test_direct_allreduce_failure_paths(nb, scenario, tmp_path):
+    """Error paths of the opt-in direct all-reduce with two PROCESSES on the one GPU (tests/tools/p2p_failure_worker.py):
+    a peer that never joins a step -> the kernels drain after NB_P2P_TIMEOUT_S and positions / energy / synchronize raise
+    NB_ERR_COMM (never garbage); a self-test that fails on one rank -> every rank votes the path down, nobody hangs.
+    Either way the single-GPU engine afterwards is bit-identical to before."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outp = str(tmp_path / "p2p_failure.json")
+    env = dict(os.environ, NB_ROOT=root, NB_OUT=outp, HSA_ENABLE_IPC_MODE_LEGACY="0", NB_SCENARIO=scenario, NB_P2P_TIMEOUT_S="1.5")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NBODY_FORCE_COMM", "NB_NO_P2P", "NB_P2P", "NB_COMM", "NB_P2P_NO_KICK",
+              "NB_TEST_P2P_FAIL_RANK"):
+        env.pop(k, None)
+    if scenario == "vote-no":
+        env["NB_TEST_P2P_FAIL_RANK"] = "1"
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29791 + (1 if scenario == "vote-no" else 0)),
+                          os.path.join(root, "tests", "tools", "p2p_failure_worker.py")], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0 and f"P2P-FAILURE-OK {scenario}" in res.stdout, res.stdout[-2000:] + res.stderr[-6000:]
+    ranks = json.load(open(outp))
+    assert len(ranks) == 2 and all(r["single_gpu_unaffected"] for r in ranks)
+    if scenario == "dead-peer":
+        errs = ranks[0]["errors"]
+        for name in ("positions", "energy", "synchronize"):
+            assert errs[name] != "no error" and errs[name][0] == -6 and "did not arrive" in errs[name][1], (name, errs[name])
+        assert ranks[0]["seconds"] < 30.0                   # bounded: a few timeouts, not the 60 s default
+    else:
+        for r in ranks:
+            assert r["p2p_state"] != 2 and "could not be set up" in r["setup"], r
+            assert "injected" in r["log"], r
+
+
+def test_failed_selftest_leaves_the_step_on_rccl():
+    """NB_P2P=auto with a self-test that fails (injected): the vote turns the direct path down and RCCL carries the step --
+    here with a 1-rank RCCL communicator, bit-identical to the communicator-less engine."""
+    import subprocess
+    import sys
+    script = r'''
+import os, sys
+sys.path.insert(0, os.environ["NB_ROOT"])
+import numpy as np
+import nbody_cosmological_simulation_amd as nb
+from nbody_cosmological_simulation_amd import runtime, galaxy, _native
+pos, vel, mass = galaxy.create_disk_galaxy(9000, seed=5, device="cpu")
+def run():
+    s = nb.GalaxySimulation(pos, vel, mass, precision_mode=nb.PrecisionMode.FLOAT64)
+    s.run(3)
+    out = s.positions.numpy().copy(), s.get_total_energy()
+    s.close()
+    return out
+x0, e0 = run()
+os.environ.update(NBODY_FORCE_COMM="1", NB_P2P="auto", NB_TEST_P2P_FAIL_RANK="0")
+runtime.init_distributed(device=0)
+x1, e1 = run()
+assert _native.lib().nb_comm_ready() == 1 and _native.lib().nb_comm_p2p_state() != 2, runtime._p2p_log
+assert runtime.allreduce_label().startswith("RCCL") and "injected" in runtime.allreduce_label(), runtime.allreduce_label()
+assert np.array_equal(x0, x1) and e0 == e1
+runtime.shutdown()
+print("VOTE-NO-RCCL-OK")
+'''
+    env = dict(os.environ, NB_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert "VOTE-NO-RCCL-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("n,d,unequal", [(1, 2, False), (65, 2, True), (1000, 3, False), (3000, 2, True), (4096, 2, False)])
 def test_small_system_single_launch_step_vs_oracle(nb, monkeypatch, n, d, unequal, mode):
