@@ -3,10 +3,18 @@
 Reference: metrics.py:12-227 (formulas restated in SURVEY.md Appendix C).  The four diagnostics run as HIP kernels
 behind the C-ABI (`nb_metrics` on a simulation's device-resident state, `nb_metrics_tensors` on caller tensors;
 csrc/nb_metrics.hip): radii, tangential speeds, the rotation-curve bins, the r-percentile order statistic, the
-enclosed masses behind the escape test and the dispersion never leave the device, and nothing is sorted.  The only
-host-side arithmetic kept is what the reference also does on the host: the 21 float32 bin edges come from
-`torch.linspace` itself, so bin membership is decided against bit-identical edges.  No torch fallback: without the
-HIP library these functions raise.
+enclosed masses behind the escape test and the dispersion never leave the device.  The two rankings take the
+reference's own route -- sort, then prefix sum: a stable device radix sort of the radii (rocPRIM, csrc/nb_sort.hip) and
+a fixed-order fp64 scan of the masses in that order.  The only host-side arithmetic kept is what the reference also does
+on the host: the 21 float32 bin edges come from `torch.linspace` itself, so bin membership is decided against
+bit-identical edges.
+
+Deviations from the reference, stated: (1) no torch fallback -- CPU tensors are staged through the GPU, and without a HIP
+device (or the library) these functions raise; (2) float16 / bfloat16 tensors are evaluated in float32 (the reference
+evaluates them in their own dtype; no script of the reference passes such tensors here, the engine-state path
+`collect_metrics` is unaffected); (3) the single-scalar helpers compute_galaxy_radius / compute_bound_fraction /
+compute_velocity_dispersion run the whole pipeline (both sorts, the scan) and return one of its results -- use
+`native_metrics` / `collect_metrics` to get all of them from one evaluation.
 """
 import ctypes as C
 from dataclasses import dataclass, field

@@ -5,7 +5,7 @@
 # prescribes (one counter group per run; FETCH_SIZE and WRITE_SIZE cannot share a pass), folded by
 # tools/pmc_summary.py.  Outputs land in gpurun_out/<tag>/; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
