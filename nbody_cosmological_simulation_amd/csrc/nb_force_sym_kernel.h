@@ -572,6 +572,8 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                         aj2[h][k] = f2{0.0f, 0.0f};
                     }
                     gj2[h] = UNIFORM ? f2{1.0f, 1.0f} : f2{packed[(size_t)D * np + p0], packed[(size_t)D * np + p0 + 64]};
+                    // general-mass grid kernel: the table-free factors are scaled by 2^-tm, the power of two rides on the masses
+                    if constexpr (HOOK == HOOK_GRID && !UNIFORM) gj2[h] = f2{ldexpf(gj2[h].x, mass_exp), ldexpf(gj2[h].y, mass_exp)};
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r)

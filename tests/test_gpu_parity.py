@@ -1271,8 +1271,8 @@ def test_tracked_max_r2_search_is_exact_over_steps(nb, monkeypatch, n, d, mode):
     """Round 3: after its first evaluation a grid-mode simulation TRACKS the farthest pair (filter + scan, two launches,
     tables built by the scan's last workgroup) instead of searching it from scratch.  The maximum must stay the exact
     fp32 maximum over all pairs at every step -- also when a star outruns the margin of the candidate test (the scan
-    then falls back to all pairs), on the one-launch small-system path (N = 3000, 2500) and on the tiled paths -- and
-    the trajectory must be bit-identical to a run that searches from scratch every time (NB_NO_TRACK)."""
+    then falls back to all pairs), on the one-launch small-system path (N = 3000, 2500: all-pairs pass) and on the tiled
+    paths -- and the trajectory must be bit-identical to a run that searches from scratch every time (NB_NO_TRACK)."""
     rng = np.random.default_rng(n + d)
     pos = (rng.standard_normal((n, d)) * 4).astype(np.float32)
     vel = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)

@@ -21,8 +21,8 @@ def timed(n, mode, mass=None, steps=400):
     return dt / steps, sim.force_kernel_name()
 
 tag = ("NB_NO_TRACK" if os.environ.get("NB_NO_TRACK") else "tracked") + (" " + os.path.basename(os.environ["NBODY_LIB"]) if os.environ.get("NBODY_LIB") else "")
-sizes = [int(x) for x in os.environ.get("GRID_TIMING_NS", "65536,3000,6000,12000").split(",")]
-for n, steps in ((65536, 400), (3000, 4000), (6000, 2000), (12000, 1000)):
+sizes = [int(x) for x in os.environ.get("GRID_TIMING_NS", "65536,1024,2048,3000,6000,12000").split(",")]
+for n, steps in ((65536, 400), (1024, 4000), (2048, 4000), (3000, 4000), (6000, 2000), (12000, 1000)):
     if n not in sizes:
         continue
     uneq = 0.5 + torch.rand(n, generator=torch.Generator().manual_seed(1))
