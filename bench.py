@@ -195,7 +195,7 @@ def collective_report(sim, runtime, nb, dist, world, n, pos, vel, mass, mode, de
     # the two carriers against each other: five steps from the same initial conditions through the direct all-reduce
     # and through RCCL (NB_NO_P2P is read when a simulation is created) must agree to rounding (their summation orders
     # differ) -- a stale or torn read on the direct path would show here
-    if rep.get("carrier") and "direct" in rep["carrier"] and rep.get("rccl_us_per_allreduce") is not None:
+    if rep.get("carrier") and rep["carrier"].startswith("direct") and rep.get("rccl_us_per_allreduce") is not None:
         def five_steps(rccl_only):
             if rccl_only:
                 os.environ["NB_NO_P2P"] = "1"

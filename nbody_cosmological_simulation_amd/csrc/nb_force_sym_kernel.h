@@ -16,9 +16,9 @@
 #ifndef NB_GRID_FACTOR_LUT
 #define NB_GRID_FACTOR_LUT 0
 #endif
-// General-mass grid kernel, 2-D, R = 4: 0 = scalar sweep (round 2), 1 = packed sweep over the whole source tile (37 VGPRs
-// spilled: measured slower, 1.17 vs 1.06 ms per INT8 step at N = 65 536), 2 = packed sweep over the source tile in two
-// halves (116 VGPRs, no spill: 1.04 ms) -- the default.  Bins identical in all three (tests/test_gpu_bins.py).
+// General-mass grid kernel, 2-D, R = 4: 0 = scalar sweep (round 2: 1.065 ms per INT8 step at N = 65 536), 1 = packed sweep
+// over the whole source tile (37 VGPRs spilled: 1.085 ms), 2 = packed sweep over the source tile in two halves (116 VGPRs,
+// no spill: 0.905 ms) -- the default (profiles/r03_grid_step_timing.txt).  Bins identical in all three.
 #ifndef NB_GRID_GENERAL_PACKED
 #define NB_GRID_GENERAL_PACKED 2
 #endif

@@ -1265,8 +1265,8 @@ def _exact_r2max_f32(pos, eps2):
     return np.float32(best)
 
 
-@pytest.mark.parametrize("mode", ["int4_sim", "custom"])
-@pytest.mark.parametrize("n,d", [(3000, 2), (2500, 3), (9000, 2), (30000, 2)])
+@pytest.mark.parametrize("mode", ["int4_sim", "custom", "custom1000"])
+@pytest.mark.parametrize("n,d", [(3000, 2), (2500, 3), (5000, 3), (9000, 2), (30000, 2)])
 def test_tracked_max_r2_search_is_exact_over_steps(nb, monkeypatch, n, d, mode):
     """Round 3: after its first evaluation a grid-mode simulation TRACKS the farthest pair (filter + scan, two launches,
     tables built by the scan's last workgroup) instead of searching it from scratch.  The maximum must stay the exact
@@ -1288,7 +1288,10 @@ def test_tracked_max_r2_search_is_exact_over_steps(nb, monkeypatch, n, d, mode):
             monkeypatch.delenv("NB_NO_TRACK", raising=False)
         else:
             monkeypatch.setenv("NB_NO_TRACK", "1")
-        sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode(mode))
+        if mode == "custom1000":               # more levels than one workgroup builds: the tables keep a launch of their own
+            sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode.CUSTOM, custom_levels=1000)
+        else:
+            sim = nb.GalaxySimulation(T(pos), T(vel), T(mass), precision_mode=nb.PrecisionMode(mode))
         got = []
         for _ in range(6):
             sim.run(1)
