@@ -141,7 +141,7 @@ generic_force_kernel(const S *__restrict__ pos, const S *__restrict__ mass, doub
     const double min_P = rnd(P, 0.01);
     // A Python scalar that MULTIPLIES / DIVIDES a half tensor stays in float (torch's CPU mul / div kernels take the
     // scalar operand in opmath precision; one that is ADDED is rounded to the tensor's dtype first -- measured on
-    // torch 2.10, tests/test_oracle_golden.py::test_torch_scalar_semantics_on_half_tensors).  Round 2 rounded G and
+    // torch 2.10 by test_torch_scalar_semantics_on_half_tensors in the CPU test suite).  Round 2 rounded G and
     // (levels - 1) to the half type here: G = 0.001 became 0.0010004 in float16, a 4e-4 error of every force, which
     // showed up as 4 % of the INT8 force values in a neighbouring force bin.
     const double Gs = rnd(opmath(Q), g.G);
