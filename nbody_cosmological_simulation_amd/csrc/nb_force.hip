@@ -19,6 +19,8 @@
 
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 namespace {
 
 using namespace nbdev;
@@ -1015,6 +1017,71 @@ track_filter_kernel(const float *__restrict__ pos, int n, float eps2, float *__r
     }
 }
 
+// Tail shared by the two tracked-search kernels: block maximum of the scanned pairs -> device-wide maximum (two 64-bit
+// atomics per workgroup) -> the LAST workgroup to arrive publishes the maximum, prepares the next evaluation's search
+// (far pair, rho bound with its margin, clean counters) and returns true with the maximum's order bits in *bits_out.
+// m: particles scanned; rho_cur / nan_flag: measured by the filter pass of this evaluation.
+__device__ __forceinline__ bool track_finish(unsigned long long best_i, unsigned long long best_j, int m, float eps2,
+                                             unsigned int rho_cur, int nan_flag, PruneState *__restrict__ ps,
+                                             unsigned long long *s_ki, unsigned long long *s_kj, int *s_mine,
+                                             unsigned int *bits_out)
+{
+    const int tid = threadIdx.x;
+    {
+        // block maximum; the partner index travels with the lane that holds the maximum
+        unsigned long long ki = best_i, kj = best_j;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long oi = __shfl_xor(ki, off, 64), oj = __shfl_xor(kj, off, 64);
+            if (oi > ki) { ki = oi; kj = oj; }
+        }
+        if ((tid & 63) == 0) { s_ki[tid >> 6] = ki; s_kj[tid >> 6] = kj; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long ki = s_ki[0], kj = s_kj[0];
+#pragma unroll
+        for (int w = 1; w < NB_BLOCK / 64; ++w)
+            if (s_ki[w] > ki) { ki = s_ki[w]; kj = s_kj[w]; }
+        if (ki) {
+            // two independent maxima: on an exact tie of r2 they may name particles of different pairs -- harmless, the
+            // pair only provides the next evaluation's lower bound, which is re-evaluated from the positions
+            atomicMax(&ps->best_i, ki);
+            atomicMax(&ps->best_j, kj);
+        }
+        __threadfence();
+        *s_mine = (atomicAdd(&ps->scan_done, 1u) == gridDim.x - 1) ? 1 : 0;
+        if (*s_mine) {
+            const unsigned long long fi = atomicMax(&ps->best_i, 0ull), fj = atomicMax(&ps->best_j, 0ull);
+            unsigned int bits = (unsigned int)(fi >> 32);
+            if (m <= 0) bits = 0u;
+            if (nan_flag) bits = 0x7fc00000u;                     // a NaN coordinate: torch's max() would be NaN
+            // a single particle (or none scanned): the diagonal pair r2 = eps2 is the maximum
+            if (bits == 0u) bits = r2_order_bits(eps2);
+            *bits_out = bits;
+            // next evaluation: this maximum's pair, the measured rho_max plus margin, clean counters
+            if (fi) { ps->pair_i = (int)(fi & 0xffffffffull); ps->pair_j = (int)(fj & 0xffffffffull); }
+            {
+                // margin for the next evaluation: twice the growth rho_max showed over this step (an escaper keeps its
+                // speed) + 1e-4 relative; the first tracked evaluation has no growth figure yet and keeps 0.5 %
+                const float rc = __uint_as_float(rho_cur);
+                const float grow = (ps->rho_prev > 0.0f) ? fmaxf(rc - ps->rho_prev, 0.0f) : 0.0025f * rc;
+                ps->rho_m = rc + 2.0f * grow + 1e-4f * rc;
+                ps->rho_prev = rc;
+            }
+            ps->seeded = (nan_flag == 0) ? 1 : 0;
+            ps->rho_cur = 0u;
+            ps->count = 0;
+            ps->nan_flag = 0;
+            ps->best_i = 0ull;
+            ps->best_j = 0ull;
+            ps->scan_done = 0u;
+        }
+    }
+    __syncthreads();
+    return *s_mine != 0;
+}
+
 constexpr int NB_TRACK_BLOCKS = 128;     // scan workgroups: every one ends in up to three same-address atomics (~17 ns each)
 
 template <int D>
@@ -1071,60 +1138,12 @@ track_scan_kernel(const float *__restrict__ pos, const float *__restrict__ cand,
         const unsigned long long kj = ((unsigned long long)best << 32) | (unsigned int)sji[bj];
         if (ki > best_i) { best_i = ki; best_j = kj; }
     }
-    // block maximum; the partner index travels with the lane that holds the maximum
-    {
-        unsigned long long ki = best_i, kj = best_j;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const unsigned long long oi = __shfl_xor(ki, off, 64), oj = __shfl_xor(kj, off, 64);
-            if (oi > ki) { ki = oi; kj = oj; }
-        }
-        if ((tid & 63) == 0) { s_ki[tid >> 6] = ki; s_kj[tid >> 6] = kj; }
+    const bool mine = track_finish(best_i, best_j, m, eps2, ps->rho_cur, ps->nan_flag, ps, s_ki, s_kj, &s_mine, &s_bits);
+    if (!mine) return;
+    if (!fuse_tables) {
+        if (tid == 0) tab->r2max_bits = s_bits;                  // the multi-block tables kernel follows
+        return;
     }
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long ki = s_ki[0], kj = s_kj[0];
-#pragma unroll
-        for (int w = 1; w < NB_BLOCK / 64; ++w)
-            if (s_ki[w] > ki) { ki = s_ki[w]; kj = s_kj[w]; }
-        if (ki) {
-            // two independent maxima: on an exact tie of r2 they may name particles of different pairs -- harmless, the
-            // pair only provides the next evaluation's lower bound, which is re-evaluated from the positions
-            atomicMax(&ps->best_i, ki);
-            atomicMax(&ps->best_j, kj);
-        }
-        __threadfence();
-        s_mine = (atomicAdd(&ps->scan_done, 1u) == gridDim.x - 1) ? 1 : 0;
-        if (s_mine) {
-            const unsigned long long fi = atomicMax(&ps->best_i, 0ull), fj = atomicMax(&ps->best_j, 0ull);
-            unsigned int bits = (unsigned int)(fi >> 32);
-            if (m <= 0) bits = 0u;
-            if (ps->nan_flag) bits = 0x7fc00000u;                 // a NaN coordinate: torch's max() would be NaN
-            // a single particle (or none scanned): the diagonal pair r2 = eps2 is the maximum
-            if (bits == 0u) bits = r2_order_bits(eps2);
-            s_bits = bits;
-            // next evaluation: this maximum's pair, the measured rho_max plus margin, clean counters
-            if (fi) { ps->pair_i = (int)(fi & 0xffffffffull); ps->pair_j = (int)(fj & 0xffffffffull); }
-            {
-                // margin for the next evaluation: twice the growth rho_max showed over this step (an escaper keeps its
-                // speed) + 1e-4 relative; the first tracked evaluation has no growth figure yet and keeps 0.5 %
-                const float rc = __uint_as_float(ps->rho_cur);
-                const float grow = (ps->rho_prev > 0.0f) ? fmaxf(rc - ps->rho_prev, 0.0f) : 0.0025f * rc;
-                ps->rho_m = rc + 2.0f * grow + 1e-4f * rc;
-                ps->rho_prev = rc;
-            }
-            ps->seeded = (ps->nan_flag == 0) ? 1 : 0;
-            ps->rho_cur = 0u;
-            ps->count = 0;
-            ps->nan_flag = 0;
-            ps->best_i = 0ull;
-            ps->best_j = 0ull;
-            ps->scan_done = 0u;
-            if (!fuse_tables) tab->r2max_bits = bits;            // the multi-block tables kernel follows
-        }
-    }
-    __syncthreads();
-    if (!s_mine || !fuse_tables) return;
     grid_tables_body<true>(tab, levels, G, eps2, min_val, nullptr, allow_fast, s_bits);
 }
 
@@ -1307,6 +1326,8 @@ hipError_t nb_launch_r2max_tracked(const float *pos, int n, int dim, float eps2,
 {
     const int blocks = (n + NB_BLOCK - 1) / NB_BLOCK;
     const int fuse = levels <= NB_LUT_MIN ? 1 : 0;
+    // (one launch instead of two -- every scan workgroup filtering for itself -- was measured slower at N = 6000 / 12 000:
+    // 52.7 / 96.9 vs 41.8 / 73.2 us per INT8 step, profiles/r03_tracked_fused_one_launch_ab.txt)
     return dispatch_dim(dim, [&](auto D) {
         constexpr int DD = decltype(D)::value;
         hipLaunchKernelGGL((track_filter_kernel<DD>), dim3(blocks), dim3(NB_BLOCK), 0, st, pos, n, eps2, cand, cand_idx, ps);
