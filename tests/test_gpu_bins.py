@@ -204,3 +204,40 @@ def test_bin_checksums_of_comm_less_shards_add_up(nb, monkeypatch, world):
         s1 += bs["sum_k"]
         s2 += bs["sum_kw"]
     assert np.array_equal(s1, ref["g13_n4096_d2/int8_sim/s1"]) and np.array_equal(s2, ref["g13_n4096_d2/int8_sim/s2"])
+
+
+@pytest.mark.parametrize("uniform", [True, False])
+@pytest.mark.parametrize("r", [2, 4])
+@pytest.mark.parametrize("case", ["narrow", "degenerate"])
+def test_packed_grid_kernels_on_narrow_and_degenerate_grids(nb, monkeypatch, case, r, uniform):
+    """States of the tables the uniform-mass packed kernel used to leave to a general-mass twin launch (round 2) and now
+    serves itself: a grid too NARROW for the bin estimate (softening 1.0, all stars within 0.05: r2 in [1, 1.01] ->
+    binary search over the thresholds, GRID_SEARCH) and a DEGENERATE grid (every r2 below the floor 0.01: values pass
+    through, quantization.py:115-116).  Forces against the oracle; bins (narrow case) against the oracle's bin matrix."""
+    from oracle import oracle as O
+    from nbody_cosmological_simulation_amd import _native
+    monkeypatch.setenv("NB_SYM", "1")
+    monkeypatch.setenv("NB_SYM_R", str(r))
+    rng = np.random.default_rng(17 + r)
+    n = 700
+    if case == "narrow":
+        pos, eps = (rng.random((n, 2)) * 0.05).astype(np.float32), 1.0
+    else:
+        pos, eps = (rng.random((n, 2)) * 2e-3).astype(np.float32), 0.05
+    mass = np.full(n, 0.8, np.float32) if uniform else (0.5 + rng.random(n)).astype(np.float32)
+    ref, dbg = O.accelerations(pos, mass, "custom", softening=eps, levels=200, debug=True)
+    sim = nb.GalaxySimulation(T(pos), torch.zeros(n, 2), T(mass), precision_mode=nb.PrecisionMode.CUSTOM, custom_levels=200,
+                              softening=eps)
+    assert sim.force_kernel_name().startswith("force_sym_kernel<float")
+    acc = sim.accelerations.numpy().astype(np.float64)
+    assert np.abs(acc - ref).max() <= 2e-6 * np.abs(ref).max()
+    if case == "narrow":
+        got = sim.quant_debug()
+        assert not got["fast_path"]
+        bs = sim.quant_bin_sums("tiled")
+        want1, want2 = checksums(dbg["d2bins"])
+        assert np.array_equal(bs["sum_k"], want1) and np.array_equal(bs["sum_kw"], want2)
+        assert bs["pairs_table_free"] == 0
+    else:
+        with pytest.raises(_native.NativeError, match="degenerate"):
+            sim.quant_bin_sums("tiled")
