@@ -1251,18 +1251,20 @@ def test_grid_mode_trajectories_vs_reference_within_its_own_noise(nb, case, mode
 
 
 def _exact_r2max_f32(pos, eps2):
-    """max over all pairs of the reference's fp32 r2 = ((dx*dx + dy*dy) [+ dz*dz]) + eps2, one rounding per op (numpy fp32)."""
-    pos = np.ascontiguousarray(pos, np.float32)
-    e = np.float32(eps2)
-    best = np.float32(0)
-    for i0 in range(0, pos.shape[0], 512):
-        d = pos[None, :, :] - pos[i0:i0 + 512, None, :]
-        sq = d * d
-        r2 = sq[..., 0] + sq[..., 1]
-        if pos.shape[1] == 3:
-            r2 = r2 + sq[..., 2]
-        best = max(best, (r2 + e).max())
-    return np.float32(best)
+    """max over all pairs of the reference's fp32 r2 = ((dx*dx + dy*dy) [+ dz*dz]) + eps2, one rounding per op (torch fp32
+    on the CPU: separate multiply and add kernels, the reference's own arithmetic)."""
+    p = torch.from_numpy(np.ascontiguousarray(pos, np.float32))
+    e = torch.tensor(float(eps2), dtype=torch.float32)
+    cols = [p[:, k].contiguous() for k in range(p.shape[1])]
+    best = torch.tensor(0.0)
+    for i0 in range(0, p.shape[0], 1024):
+        r2 = None
+        for c in cols:
+            d = c[None, :] - c[i0:i0 + 1024, None]
+            sq = d * d
+            r2 = sq if r2 is None else r2 + sq
+        best = torch.maximum(best, (r2 + e).max())
+    return np.float32(best.item())
 
 
 @pytest.mark.parametrize("mode", ["int4_sim", "custom", "custom1000"])
