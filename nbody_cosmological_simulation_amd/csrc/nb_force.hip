@@ -662,13 +662,19 @@ __device__ __forceinline__ void grid_tables_body(GridTables *__restrict__ tab, i
     }
     __shared__ int s_last;
     __shared__ float s_thr[NB_LUT_MIN], s_lut[NB_LUT_MIN], s_red[NB_LUT_MIN], s_par[4];
+    __shared__ double s_lg2[2];          // log2 of the first / last factor, taken by their own threads (off the serial tail)
     const int k = (FUSED ? 0 : blockIdx.x) * NB_LUT_MIN + threadIdx.x;
     const int tables_blocks = FUSED ? 1 : gridDim.x;
     const float r2max = __uint_as_float(r2max_bits);
     const float tmin = (eps2 < min_val) ? min_val : eps2;        // diagonal entries: r2 == eps2
     const float tmax = (r2max < min_val) ? min_val : r2max;
-    const float lmin = logf_cr(tmin);
-    const float lmax = logf_cr(tmax);
+    // the two correctly rounded logarithms head every thread's dependency chain: even lanes take one, odd lanes the
+    // other, and neighbours swap (all 256 threads are active here)
+    const bool odd = (threadIdx.x & 1) != 0;
+    const float lg_mine = logf_cr(odd ? tmax : tmin);
+    const float lg_other = __shfl_xor(lg_mine, 1, 64);
+    const float lmin = odd ? lg_other : lg_mine;
+    const float lmax = odd ? lg_mine : lg_other;
     const float range = __fsub_rn(lmax, lmin);
     const float lm1 = (float)(levels - 1);
     const bool degenerate = range < 1e-10f || levels > NB_MAX_LUT;
@@ -694,6 +700,8 @@ __device__ __forceinline__ void grid_tables_body(GridTables *__restrict__ tab, i
         tab->qval[ka] = q;
         tab->lut[ka] = w;
         s_lut[ka - base_l] = w;
+        if (ka == 0) s_lg2[0] = log2((double)w);
+        if (ka == levels - 1) s_lg2[1] = log2((double)w);
     }
     if (kb >= 0) {
         const int k = kb;
@@ -736,7 +744,7 @@ __device__ __forceinline__ void grid_tables_body(GridTables *__restrict__ tab, i
         s_thr[k - base_l] = thr;
     }
     __syncthreads();               // every thread of this block has read tab->r2max_bits and written its entry
-    if (!FUSED) {
+    if (!FUSED && gridDim.x > 1) {       // (single-block tables -- every grid up to 256 levels -- need no arrival count)
         if (threadIdx.x == 0) {
             __threadfence();
             s_last = (atomicAdd(&tab->blocks_done, 1u) == gridDim.x - 1) ? 1 : 0;
@@ -757,8 +765,8 @@ __device__ __forceinline__ void grid_tables_body(GridTables *__restrict__ tab, i
         const double w0 = (double)s_lut[0], w1 = (double)s_lut[min(levels, NB_LUT_MIN) - 1];
         double c1 = 0.0, cm = 0.0;
         if (fast_try && w0 > 0.0 && w1 > 0.0 && w0 < 1e30 && w1 < 1e30) {
-            c1 = (log2(w1) - log2(w0)) / (double)(levels - 1);
-            cm = log2(w0) + c1 * (double)kc;            // log2 of the factor of the middle bin
+            c1 = (s_lg2[1] - s_lg2[0]) / (double)(levels - 1);
+            cm = s_lg2[0] + c1 * (double)kc;            // log2 of the factor of the middle bin
         } else {
             fast_try = false;
         }
@@ -788,22 +796,16 @@ __device__ __forceinline__ void grid_tables_body(GridTables *__restrict__ tab, i
         if (!(my_rel == my_rel)) my_rel = 1.0f;
     }
     float maxdev = 0.0f, maxrel = 0.0f;
-    if (fast_try) {                 // block-uniform
-        s_red[threadIdx.x] = my_dev;
-        __syncthreads();
-        for (int st = NB_LUT_MIN / 2; st >= 1; st >>= 1) {
-            if ((int)threadIdx.x < st) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + st]);
-            __syncthreads();
+    if (fast_try) {                 // block-uniform: both maxima by wave shuffles + one exchange through LDS
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            my_dev = fmaxf(my_dev, __shfl_xor(my_dev, off, 64));
+            my_rel = fmaxf(my_rel, __shfl_xor(my_rel, off, 64));
         }
-        maxdev = s_red[0];
+        if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = my_dev; s_red[8 + (threadIdx.x >> 6)] = my_rel; }
         __syncthreads();
-        s_red[threadIdx.x] = my_rel;
-        __syncthreads();
-        for (int st = NB_LUT_MIN / 2; st >= 1; st >>= 1) {
-            if ((int)threadIdx.x < st) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + st]);
-            __syncthreads();
-        }
-        maxrel = s_red[0];
+#pragma unroll
+        for (int w = 0; w < NB_LUT_MIN / 64; ++w) { maxdev = fmaxf(maxdev, s_red[w]); maxrel = fmaxf(maxrel, s_red[8 + w]); }
     }
     if (fin && ps) {
         // the pruned max-r2 search is finished: seed the tracked search of the next evaluation with its far pair
