@@ -1303,9 +1303,10 @@ def test_tracked_max_r2_search_is_exact_over_steps(nb, monkeypatch, n, d, mode):
 
     tracked, scratch = run(True), run(False)
     for step, ((r_t, l_t, x_t), (r_s, l_s, x_s)) in enumerate(zip(tracked, scratch)):
-        want = _exact_r2max_f32(x_t, eps2)
-        assert r_t == want, (step, r_t, want)
-        assert r_s == want and l_t == l_s
+        assert r_t == r_s and l_t == l_s, (step, r_t, r_s)
+        if n < 20000 or step % 2 == 1:          # the host-side exact maximum of 9e8 pairs takes seconds: every other step there
+            want = _exact_r2max_f32(x_t, eps2)
+            assert r_t == want, (step, r_t, want)
         assert np.array_equal(x_t, x_s), f"step {step}: the tracked search changed the trajectory"
     # the escaper did become a member of the farthest pair
     assert tracked[-1][0] > tracked[0][0]
