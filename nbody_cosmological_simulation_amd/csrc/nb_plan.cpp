@@ -111,10 +111,10 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
     // A workgroup sweeps 4 rows x cl source tiles.  ~2000 workgroups per launch: with tail smoothing
     // (below) measured at N=65536 (R=4): cl = 1/2/4/6/8/16 -> step 1.28/1.28/1.27/1.29/1.29/1.47 ms
     // (small cl pays in row-slot traffic, large cl in load balance).
-    // The grid-mode kernels (table copies + row sums in LDS per workgroup, longer pair loop) want work items half as long:
-    // measured per step at N = 65536, cl = 1 / 2 / 4: INT8 784 / 783 / 810 us, INT4 756 / 752 / 773, CUSTOM 750 / 747 / 770
-    // (FLOAT32 514 / 504 / 506, FLOAT64 1205 / 1198 / 1198: unchanged targets there).
-    const long long target_items = (!is_f64 && in.mode >= NB_INT8_SIM) ? 4096 : 2048;
+    // The fp32 kernels (items half as long as fp64 ones; the grid-mode kernels also copy their tables per workgroup) want
+    // twice the work items: measured per step at N = 65536, cl = 1 / 2 / 4: INT8 784 / 783 / 810 us, INT4 756 / 752 / 773,
+    // CUSTOM 750 / 747 / 770, FLOAT32 514 / 504 / 506 (3-D force launch: 0.671 / 0.672 / 0.684 ms); FLOAT64 1205 / 1198 / 1198.
+    const long long target_items = is_f64 ? 2048 : 4096;
     int cl = (int)(owned_pairs / target_items / 4);
     cl = std::max(1, std::min(cl, 16));
     if (knobs.sym_cl > 0) cl = knobs.sym_cl;
