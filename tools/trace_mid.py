@@ -1,3 +1,5 @@
+"""One grid-mode run at a chosen size, for `rocprofv3 --kernel-trace --stats -- python3 tools/trace_mid.py N MODE`
+(per-kernel durations of a mid / small-N step: profiles/README.md, round 3)."""
 import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import nbody_cosmological_simulation_amd as nb
