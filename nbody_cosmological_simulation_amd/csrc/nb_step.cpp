@@ -21,8 +21,9 @@ struct NbTuning {
                                         // one-launch small-system path the all-pairs pass costs the same (measured INT8 / CUSTOM
                                         // N = 3000: 31.3 / 27.1 vs 31.0 / 26.7 us per step: the table construction by a single
                                         // workgroup is what is left there, not the search)
-    int red_mm_max_blocks = 512;        // INT8 / INT4: the reduction also hands out force min / max partials up to
-                                        // N = 32 768 (beyond, every finish workgroup would fold thousands of them)
+    int red_mm_max_blocks = 1024;       // INT8 / INT4: the reduction also hands out force min / max partials up to
+                                        // N = 65 536 (one launch fewer: INT8 step 785.8 -> 784.2 us there; beyond, every
+                                        // finish workgroup would fold thousands of them)
     int small_max_f64 = 4096;           // one-launch step: fp64 4.9 / 7.9 / 11.4 / 16.9 us per step at N = 1024 ... 4096
     int small_max_f32 = 3072;           // fp32 storage: above, 32 lanes per target and the tiled path is ahead
     int small_fuse_tables_max_n = 2048; // small grid steps: max-r2 launch also builds the tables up to here
