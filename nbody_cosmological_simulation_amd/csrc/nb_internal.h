@@ -282,6 +282,7 @@ hipError_t nb_launch_generic_force(const void *pos, const void *mass, int storag
 
 // ---- one-launch step for small systems (nb_small.hip) -------------------------------------------------------------
 int nb_small_lanes(int n);
+int nb_small_block(int n);          // threads per workgroup of the one-launch step at this size (256 or 512)
 hipError_t nb_launch_small_step(const void *pos_in, void *pos_out, void *vel, void *acc, const void *mass, int n, int dim,
                                 int is_f64, int hook, double G, double eps2, double half_dt, double dt,
                                 int do_kick /* 0 force only, 1 + closing kick, 2 + next opening kick + drift into pos_out */,

@@ -17,6 +17,10 @@
 // order for r2 without fma, cast hooks, v_rsq_f32 + first-order correction, fp32 products summed in fp64).
 #include "nb_device.h"
 
+#include <cstdlib>
+
+int nb_small_block(int n);
+
 namespace {
 
 using namespace nbdev;
@@ -49,14 +53,17 @@ template <> __device__ __forceinline__ float axpy_sep<float>(float a, float b, f
 // BINS (grid hook only): the same body with the quant-bin read-out -- per-target integer checksums s1 = sum_j k,
 // s2 = sum_j k ((j mod 65521) + 1) of the bin every pair was given, by whichever route the production code took
 // (table-free estimate / wave ballot / threshold fallback); bin_out = {s1[n], s2[n], {table-free pairs, table pairs}}.
-template <typename T, int D, int HOOK, int S, bool BINS = false>
-__global__ void __launch_bounds__(NB_BLOCK)
+// BS: threads per workgroup.  Every workgroup streams ALL sources through its LDS, so the L2 -> LDS traffic of a step is
+// N^2 * 24 B / (targets per workgroup): 512 threads (8 targets of 64 lanes) halve it against 256; used up to N = 2048,
+// where all workgroups still run in one round (nb_small_block).
+template <typename T, int D, int HOOK, int S, bool BINS = false, int BS = NB_BLOCK>
+__global__ void __launch_bounds__(BS)
 small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__restrict__ vel, T *__restrict__ acc,
                   const T *__restrict__ mass, int n, T G, T eps2, T half_dt, T dt, int do_kick,
                   const GridTables *__restrict__ tab, double *__restrict__ part, unsigned long long *__restrict__ bin_out)
 {
     constexpr bool F64 = sizeof(T) == 8;
-    constexpr int TG = NB_BLOCK / S;                 // targets per workgroup
+    constexpr int TG = BS / S;                       // targets per workgroup
     __shared__ T sx[D][SM_TILE];
     __shared__ T sg[SM_TILE];                        // G * m_j (fp32: the reference's (1/p * G) * m_j order is kept below)
     // grid hook (INT8 / INT4 / CUSTOM up to 256 levels): the evaluation's tables (nb_force.hip grid_tables_kernel)
@@ -67,7 +74,7 @@ small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__re
     int g_levels = 0, g_tm = 0;
     if constexpr (HOOK == HOOK_GRID) {
         g_levels = tab->levels;
-        for (int k = tid; k <= NB_LUT_MIN; k += NB_BLOCK) {
+        for (int k = tid; k <= NB_LUT_MIN; k += BS) {
             s_thr[k] = (k <= g_levels) ? tab->thr[k] : __builtin_inff();     // thr[levels] = NaN sentinel, +inf padding
             s_lut[k] = (k < g_levels) ? tab->lut[k] : 0.0f;
         }
@@ -96,7 +103,7 @@ small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__re
         const int cnt_ld = min(SM_TILE, (min(SM_TILE, n - j0) + STRIDE - 1) / STRIDE * STRIDE);
         // (a "flat" variant -- consecutive threads reading consecutive elements of the (N, D) array and scattering them
         // into the component arrays -- measured slower on the same box: 6.8 vs 5.4 us per step at N = 1024 fp64)
-        for (int t = tid; t < cnt_ld; t += NB_BLOCK) {
+        for (int t = tid; t < cnt_ld; t += BS) {
             const int j = j0 + t;
             if (j < n) {
 #pragma unroll
@@ -234,7 +241,7 @@ small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__re
             atomicAdd(&bin_out[2 * (size_t)n + 1], (unsigned long long)bexact);
         }
     }
-    __shared__ double s_mm[NB_BLOCK / 16][2];        // INT8 / INT4: min / max of this workgroup's force components
+    __shared__ double s_mm[BS / 16][2];        // INT8 / INT4: min / max of this workgroup's force components
     double lo = __builtin_inf(), hi = -__builtin_inf();
     if (live && l == 0) {
 #pragma unroll
@@ -277,8 +284,14 @@ hipError_t launch_s(const T *pos_in, T *pos_out, T *vel, T *acc, const T *mass, 
                     unsigned long long *bin_out = nullptr)
 {
 #define NB_SMALL(SS)                                                                                                       \
-    hipLaunchKernelGGL((small_step_kernel<T, D, HOOK, SS, BINS>), dim3((n + NB_BLOCK / SS - 1) / (NB_BLOCK / SS)), dim3(NB_BLOCK), 0, \
-                       st, pos_in, pos_out, vel, acc, mass, n, (T)G, (T)eps2, (T)half_dt, (T)dt, do_kick, tab, part, bin_out)
+    do {                                                                                                                   \
+        if (nb_small_block(n) == 512)                                                                                      \
+            hipLaunchKernelGGL((small_step_kernel<T, D, HOOK, SS, BINS, 512>), dim3((n + 512 / SS - 1) / (512 / SS)), dim3(512), 0, \
+                               st, pos_in, pos_out, vel, acc, mass, n, (T)G, (T)eps2, (T)half_dt, (T)dt, do_kick, tab, part, bin_out); \
+        else                                                                                                               \
+            hipLaunchKernelGGL((small_step_kernel<T, D, HOOK, SS, BINS, 256>), dim3((n + 256 / SS - 1) / (256 / SS)), dim3(256), 0, \
+                               st, pos_in, pos_out, vel, acc, mass, n, (T)G, (T)eps2, (T)half_dt, (T)dt, do_kick, tab, part, bin_out); \
+    } while (0)
     if (lanes == 64) NB_SMALL(64);
     else if (lanes == 32) NB_SMALL(32);
     else NB_SMALL(16);
@@ -290,6 +303,16 @@ hipError_t launch_s(const T *pos_in, T *pos_out, T *vel, T *acc, const T *mass, 
 
 // lanes per target by size: enough lanes to keep a lane's source loop short, few enough that the source tiles every
 // workgroup re-reads from L2 stay small (N^2 * S * 0.1 bytes per step)
+// threads per workgroup of the one-launch step (see small_step_kernel): NB_SMALL_BLOCK overrides (A/B)
+int nb_small_block(int n)
+{
+    static const int forced = getenv("NB_SMALL_BLOCK") ? atoi(getenv("NB_SMALL_BLOCK")) : 0;
+    if (forced == 256 || forced == 512) return forced;
+    // measured fp64 us per step, 256 / 512 / 1024 threads: N = 1024 5.4 / 5.2 / -, 2048 8.4 / 7.5 / -, 2500 10.9 / 11.3 / 11.3,
+    // 3000 11.9 / 12.5 / 12.4, 4096 17.2 / 17.4 / 24.8: the larger workgroup wins while all of them fit the chip in one round
+    return n <= 2048 ? 512 : 256;
+}
+
 int nb_small_lanes(int n)
 {
     // measured (fp32, us per step at N = 1024 / 2048 / 3000 / 4096): 16 lanes 6.8 / 11.4 / 15.9 / 20.5, 32 lanes

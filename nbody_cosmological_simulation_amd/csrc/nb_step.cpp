@@ -474,7 +474,7 @@ int step_small(nb_sim *s, int nsteps, bool opened)
         if (int rc = prof_end(s, slot)) return rc;
         if (fq)      // one min / max pair per workgroup of the force launch
             HIPCHK(nb_launch_force_quant_finish((float *)s->acc, nd(s), mode_levels(c), s->small_part,
-                                                (c.n + NB_BLOCK / lanes - 1) / (NB_BLOCK / lanes), s->scalars, s->fbins,
+                                                (c.n + nb_small_block(c.n) / lanes - 1) / (nb_small_block(c.n) / lanes), s->scalars, s->fbins,
                                                 (float *)s->vel, (float *)s->pos, c.dt / 2, c.dt, last ? 1 : 2, s->stream));
         else if (!last)
             std::swap(s->pos, s->pos_alt);
