@@ -310,7 +310,9 @@ int nb_small_block(int n)
     if (forced == 256 || forced == 512) return forced;
     // measured fp64 us per step, 256 / 512 / 1024 threads: N = 1024 5.4 / 5.2 / -, 2048 8.4 / 7.5 / -, 2500 10.9 / 11.3 / 11.3,
     // 3000 11.9 / 12.5 / 12.4, 4096 17.2 / 17.4 / 24.8: the larger workgroup wins while all of them fit the chip in one round
-    return n <= 2048 ? 512 : 256;
+    // ... and again above N = 3072 (fp64 only gets there), with 64 lanes per target: N = 4096 15.7 (512 x 64) vs 17.2
+    // (256 x 32) / 17.9 (256 x 64)
+    return (n <= 2048 || n > 3072) ? 512 : 256;
 }
 
 int nb_small_lanes(int n)
@@ -318,7 +320,7 @@ int nb_small_lanes(int n)
     // measured (fp32, us per step at N = 1024 / 2048 / 3000 / 4096): 16 lanes 6.8 / 11.4 / 15.9 / 20.5, 32 lanes
     // 5.4 / 8.5 / 12.5 / 15.5, 64 lanes 4.7 / 7.5 / 10.3 / 15.8 (two-launch path: 8.0 / 9.5 / 11.5 / 16.0);
     // fp64: 64 lanes 4.9 / 7.9 / 11.4 / 17.2, 32 lanes 5.5 / 8.8 / 13.3 / 16.9 (two-launch path: 8.3 / 12.5 / 19.1 / 21.3)
-    return n <= 3072 ? 64 : 32;
+    return 64;       // (32 lanes above N = 3072 with 256-thread workgroups until round 3; 512 x 64 is ahead there now)
 }
 
 hipError_t nb_launch_small_step(const void *pos_in, void *pos_out, void *vel, void *acc, const void *mass, int n, int dim,

@@ -25,7 +25,7 @@ struct NbTuning {
                                         // N = 65 536 (one launch fewer: INT8 step 785.8 -> 784.2 us there; beyond, every
                                         // finish workgroup would fold thousands of them)
     int small_max_f64 = 4096;           // one-launch step: fp64 4.9 / 7.9 / 11.4 / 16.9 us per step at N = 1024 ... 4096
-    int small_max_f32 = 3072;           // fp32 storage: above, 32 lanes per target and the tiled path is ahead
+    int small_max_f32 = 3072;           // fp32 storage: above, the tiled path is ahead (FLOAT32) or level (INT8 / INT4)
     int small_fuse_tables_max_n = 2048; // small grid steps: max-r2 launch also builds the tables up to here
 };
 static const NbTuning g_tune{};
@@ -411,10 +411,10 @@ bool small_ok(const nb_sim *s)
 {
     const nb_config &c = s->cfg;
     const int sdt = s->is_f64 ? NB_F64 : NB_F32;
-    // fp32 storage: above 3072 the one-launch kernel runs with 32 lanes per target and the tiled path is ahead
-    // (measured us per step, one launch vs tiled: FLOAT32 N = 3200 13.7 / 10.7, 3584 14.9 / 10.9, 4096 15.9 / 13.4;
-    // CUSTOM 3584 32.8 / 30.9; INT4 4096 39.5 / 40.1 -- equal; up to 3072 one launch wins or ties everywhere);
-    // fp64 keeps it to 4096 (17.2 against 18.9)
+    // fp32 storage: above 3072 the tiled path is ahead (measured us per step with 512 x 64 workgroups, one launch vs
+    // tiled: FLOAT32 N = 3300 13.2 / 10.8, 3584 13.5 / 11.0, 4096 14.7 / 13.3; INT8 3584 33.2 / 35.7, 4096 35.3 / 36.5 and
+    // INT4 3840 37.2 / 34.3, 4096 42.3 / 43.8 -- within the run-to-run spread of the max-r2 search; up to 3072 one
+    // launch wins or ties everywhere); fp64 keeps it to 4096 (15.7 against 18.9)
     const int nmax = s->knobs.small_max > 0 ? s->knobs.small_max : (s->is_f64 ? g_tune.small_max_f64 : g_tune.small_max_f32);
     if (s->knobs.no_smalln || c.n > nmax || comm_active(s) || c.nranks != 1 || !s->have_acc) return false;
     if (grid_mode(c.mode) && (s->is_f64 || mode_levels(c) > NB_LUT_MIN || mode_levels(c) < 2)) return false;
