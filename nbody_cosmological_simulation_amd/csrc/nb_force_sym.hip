@@ -480,3 +480,13 @@ hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, cons
 #undef NB_RED
     return hipGetLastError();
 }
+
+#ifdef NB_WG_TRACE
+// experimental builds only: copy the workgroup trace of the last force_sym_kernel launch of this library (tools/wg_trace.py)
+extern "C" int nb_debug_wg_trace(unsigned long long *host, int nwg)
+{
+    if (nwg > NB_WG_TRACE_MAX) nwg = NB_WG_TRACE_MAX;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(nb_wg_trace_buf), sizeof(unsigned long long) * 8 * (size_t)nwg) == hipSuccess ? nwg : -1;
+}
+#endif

@@ -441,6 +441,13 @@ __device__ __forceinline__ void sweep_pk(const float (&xi)[R][D], const float (&
     }
 }
 
+#ifdef NB_WG_TRACE
+// experimental builds only (make exp EXPFLAGS=-DNB_WG_TRACE; tools/wg_trace.py): where and when every workgroup of the
+// last force launch ran -- {start, end} of the constant 100 MHz clock, XCC_ID, and per wave HW_ID | (end - start) << 32
+constexpr int NB_WG_TRACE_MAX = 16384;
+__device__ unsigned long long nb_wg_trace_buf[NB_WG_TRACE_MAX][8];
+#endif
+
 // T = double: FLOAT64 mode on fp64 state.  T = float: every fp32-state mode (HOOK selects it).
 // packed  [D+1][NP] of T : x, y, (z), mass factor (G*m, or m for HOOK_GRID whose LUT carries G);
 //                          padding particles sit far away (see pack_kernel).
@@ -469,6 +476,10 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
     __shared__ float s_thr[HOOK == HOOK_GRID ? LPC + 1 : 1];
     __shared__ float s_lut[HOOK == HOOK_GRID ? LPC + 1 : 1];
 
+#ifdef NB_WG_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+    const unsigned long long trace_c0 = __builtin_readcyclecounter();
+#endif
     const SymWork wk = work[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int I = wk.tile_i + wave;             // this wave's target tile (wave-uniform)
@@ -689,6 +700,18 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
         for (int k = 0; k < D; ++k)
             rowslab[((size_t)slot * D + k) * B + r * 64 + lane] =
                 (UNIFORM && HOOK == HOOK_GRID) ? row_ref(r, k) * (double)gscale : row_ref(r, k);
+#ifdef NB_WG_TRACE
+    if (lane == 0 && blockIdx.x < NB_WG_TRACE_MAX)
+        nb_wg_trace_buf[blockIdx.x][4 + wave] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |     // HW_REG_HW_ID
+                                                ((wall_clock64() - trace_t0) << 32);
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < NB_WG_TRACE_MAX) {
+        nb_wg_trace_buf[blockIdx.x][0] = trace_t0;
+        nb_wg_trace_buf[blockIdx.x][1] = wall_clock64();
+        nb_wg_trace_buf[blockIdx.x][2] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+        nb_wg_trace_buf[blockIdx.x][3] = __builtin_readcyclecounter() - trace_c0;       // shader clocks
+    }
+#endif
 }
 
 template <typename T, int D, int R, int HOOK, int LPC, bool BINS = false>

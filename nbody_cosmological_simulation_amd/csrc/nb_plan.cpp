@@ -20,7 +20,7 @@ NbKnobs nb_read_knobs()
     k.sym_r = env_int("NB_SYM_R", 0);
     k.sym_cl = std::max(0, env_int("NB_SYM_CL", 0));
     k.sym_split = env_int("NB_SYM_SPLIT", 0);
-    if (k.sym_split != 1 && k.sym_split != 2 && k.sym_split != 4 && k.sym_split != 8) k.sym_split = 0;
+    if (k.sym_split < 1 || k.sym_split > 16) k.sym_split = 0;
     k.tail_pieces = env_int("NB_SYM_TAIL", 0);
     if (k.tail_pieces != 2 && k.tail_pieces != 4 && k.tail_pieces != 8 && k.tail_pieces != 16) k.tail_pieces = 0;
     k.r_onesided = env_int("NB_R", 0);
@@ -85,7 +85,7 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
     // The choice between this plan and the one-sided source blocks must be the same on every rank (their
     // partial sums are added): it may only depend on rank-independent quantities.  Fewer super-rows than
     // ranks would leave a rank without work; the slab budget is checked for the worst case (every owned
-    // super-row cut into eight pieces).
+    // super-row cut into eight pieces -- the most the plan itself chooses; NB_SYM_SPLIT is budgeted by its own value).
     const size_t el = is_f64 ? sizeof(double) : sizeof(float);
     if (SR < P) return;
     {
@@ -135,11 +135,27 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
         for (int S = 0; S < SR; ++S) split_of[S] = knobs.sym_split;
     } else if (sp.r == 4 && items < 1000) {
         // Mid-sized systems on the R = 4 tiling: too few work items to fill 1024 workgroup slots with four waves per SIMD,
-        // and a whole sweep (64 steps x 16 pairs) is long -- every sweep in 4 pieces (8 below 100 items).  Measured
-        // fp64 us per step with 1 / 2 / 4 / 8 pieces: N = 6144 (84 items) 51.4 / 30.2 / 28.5 / 27.9, 8192 (144) 52.3 /
-        // 45.4 / 39.1 / 39.9, 12 288 (312) 81.1 / 65.6 / 60.9 / 62.7, 16 384 (544) 116 / 102 / 96.7 / 101,
-        // 24 576 (1200) 192 / 195 / 196 / 216.
-        const int pieces = items < 100 ? 8 : 4;
+        // and a whole sweep (64 steps x 16 pairs) is long -- every sweep is cut into pieces (nsp need not divide 64).
+        // Where the time goes (workgroup trace of the force launch, tools/wg_trace.py, fp64 N = 8192, 144 items): the
+        // dispatcher spreads workgroups evenly over the CUs and a SIMD serves its resident waves oldest first, so the
+        // launch lasts rounds = ceil(workgroups / CUs) pieces back to back on the fullest CUs (4 pieces: 576 workgroups,
+        // 64 CUs hold three -> 31.7 us; 3 pieces: 432, two per CU -> 29.4 us); a SIMD with one resident wave issues a
+        // rotation step of 16 pairs in ~0.7 us, with four in 0.55 us; and every piece costs the reduction one more row
+        // slot and slab entry to read (reduction + launch gap: 6.3 / 7.9 / 9.8 / 13.2 us with 3 / 4 / 5 / 7 pieces).
+        // The pieces per sweep minimise that model; its choice is within 3 % of the best measured one at every size
+        // of the sweep behind it (profiles/r03_mid_split_sweep.txt; fp64 us per step, pieces = 4 -> chosen: N = 5632
+        // 28.0 -> 24.2, 6144 28.7 -> 25.0, 8192 39.3 -> 35.9, 10 240 50.6 -> 47.2, 14 336 79.5 -> 76.9).
+        int pieces = 4;
+        if (items < 500) {
+            const double t_step[4] = {0.70, 0.60, 0.62, 0.55};      // us per rotation step with 1 .. 4 resident waves per SIMD
+            double best = 1e30;
+            for (int nsp : {2, 3, 4, 5, 6, 8}) {
+                const long long wgs = items * nsp, rounds = (wgs + in.cus - 1) / in.cus;
+                const double cost = rounds * ((64 + nsp - 1) / nsp + 1) * t_step[std::min<long long>(rounds, 4) - 1] +
+                                    1.5 * (double)wgs / in.cus;
+                if (cost < best) { best = cost; pieces = nsp; }
+            }
+        }
         for (int S = 0; S < SR; ++S) split_of[S] = pieces;
     } else if (items <= 100) {
         // Very small systems are bound by the LATENCY of one 64-step sweep (~4 us: a bpermute + a dependent VALU chain
@@ -173,8 +189,10 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
         for (int w = 0; w < 4; ++w) { sp.row_slot0[j0 + w] = slots + w * per_row; sp.row_nslots[j0 + w] = per_row; }
         for (int ch = 0; ch < nch; ++ch)
             for (int q = 0; q < nsp; ++q) {
+                // piece q of nsp: rotation steps [64 q / nsp, 64 (q + 1) / nsp) -- nsp need not divide 64
+                const int s0 = 64 * q / nsp, s1 = 64 * (q + 1) / nsp;
                 SymWork wk{j0, j0 + ch * cl, std::min(T, j0 + (ch + 1) * cl), slots + ch * nsp + q, per_row,
-                           ncol + q, q * (64 / nsp), 64 / nsp};
+                           ncol + q, s0, s1 - s0};
                 items_v.push_back(wk);
             }
         slots += 4 * per_row;

@@ -15,7 +15,7 @@ struct NbKnobs {
     int sym = -1;          // NB_SYM: -1 by size, 0 never, 1 always, 2 also for comm-less shards (tests)
     int sym_r = 0;         // NB_SYM_R: targets per lane (1, 2, 4); 0 = by size
     int sym_cl = 0;        // NB_SYM_CL: source tiles per work item; 0 = by work
-    int sym_split = 0;     // NB_SYM_SPLIT: cut EVERY sweep into 1 / 2 / 4 / 8 pieces; 0 = tail smoothing only
+    int sym_split = 0;     // NB_SYM_SPLIT: cut EVERY sweep into 1 ... 16 pieces; 0 = the plan's own choice
     int tail_pieces = 0;   // NB_SYM_TAIL: pieces per sweep of the tail-smoothed super-rows (4 or 8); 0 = auto
     int r_onesided = 0;    // NB_R: targets per thread of the one-sided fp64 kernel
     bool no_prune = false;   // NB_NO_PRUNE: all-pairs max-r2 scan at any N
