@@ -131,6 +131,11 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
     long long items = 0;
     for (int S = 0; S < SR; ++S)
         if (ord[S] >= 0) { nch_of[S] = (T - 4 * S + cl - 1) / cl; items += nch_of[S]; }
+    // (Round 3 also tried DECREASING chunks towards the end of the work list -- cl / 2, cl / 4 source tiles, then half and
+    // quarter sweeps for the trailing super-rows -- because a CU drains through 3, 2, 1 resident waves per SIMD when the
+    // list runs dry.  The workgroup trace confirmed full residency until 1.05 of 1.15 ms instead of 0.75, and the launch
+    // was no faster: fp64 N = 65 536 1203.7 -> 1204.9 us per step, 131 072 4817 -> 4771, FLOAT32 503.6 -> 509.0, INT8 785.1 ->
+    // 782.3 (profiles/r03_guided_chunks_ab.txt).  One or two fp64 waves keep a SIMD's issue port nearly as busy as four.)
     if (knobs.sym_split) {
         for (int S = 0; S < SR; ++S) split_of[S] = knobs.sym_split;
     } else if (sp.r == 4 && items < 1000) {
