@@ -176,8 +176,12 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
     } else if (items > wg_slots / 2) {
         long long rem = items % wg_slots;
         // a single round of workgroups has nothing to hide a straggler behind: finer pieces there
-        const int pieces = knobs.tail_pieces ? knobs.tail_pieces : (items < 2 * wg_slots ? 8 : 4);
-        if (rem > 0 && rem <= wg_slots / 2) {
+        // R = 2 (fp32 family below N = 20 480): a whole sweep is only 64 steps x 4 pairs, finer pieces than halves cost
+        // more than they smooth (FLOAT32 us per step, none / 2 / 4 / 8 pieces: N = 11 776 38.9 / 35.7 / 36.8 / 40.4,
+        // 12 288 39.4 / 39.4 / 40.1 / 45.1, 13 312 45.6 / 45.5 / 48.0 / 52.6, 13 824 -- 488 items over -- 46.0 / 47.9 /
+        // 51.0 / 54.8, 16 384 63.6 / 59.6 / 59.8 / 63.1; profiles/r03_tail_pieces_sweep.txt)
+        const int pieces = knobs.tail_pieces ? knobs.tail_pieces : (sp.r == 2 ? 2 : (items < 2 * wg_slots ? 8 : 4));
+        if (rem > 0 && rem <= (sp.r == 2 ? 3 * wg_slots / 8 : wg_slots / 2)) {
             for (int S = SR - 1; S >= 0 && rem > 0; --S)      // trailing (shortest) super-rows first
                 if (ord[S] >= 0) { split_of[S] = pieces; rem -= nch_of[S]; }
         }
