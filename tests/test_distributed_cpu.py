@@ -109,7 +109,9 @@ def _plan(n, dim, rank, world, is_f64=True, multi=True, mode=0, cus=256):
     return out
 
 
-@pytest.mark.parametrize("n,is_f64", [(9000, True), (65536, True), (262144, False), (20481, True), (1024, True), (1100, False)])
+@pytest.mark.parametrize("n,is_f64", [(9000, True), (65536, True), (262144, False), (20481, True), (1024, True), (1100, False),
+                                      # mid sizes whose sweeps the cost model cuts into 3 / 5 / 6 pieces (unequal lengths)
+                                      (8192, True), (6656, True), (5632, True), (12288, False)])
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
 def test_symmetric_plans_cover_every_tile_pair_once(monkeypatch, n, is_f64, world):
     """The multi-GPU partition of the headline sizes is snake-dealt target super-rows with pair symmetry
@@ -119,7 +121,10 @@ def test_symmetric_plans_cover_every_tile_pair_once(monkeypatch, n, is_f64, worl
     plans = [_plan(n, 2, r, world, is_f64=is_f64) for r in range(world)]
     if not plans[0]["enabled"]:
         # fewer super-rows than ranks: EVERY rank falls back to the one-sided source blocks
-        assert n <= 1100 and world >= 3 and not any(p["enabled"] for p in plans)
+        # (n <= 1100: tiles of 64 / 128; the fp64 mid sizes: tiles of 256 -> N = 6656 has 7 super-rows, 5632 has 6)
+        sr_max = -(-(-(-n // 256)) // 4) if n > 1100 else 5
+        assert world > sr_max or (n <= 1100 and world >= 3)
+        assert not any(p["enabled"] for p in plans)
         return
     assert all(p["enabled"] for p in plans)
     p0 = plans[0]
@@ -167,6 +172,36 @@ def test_symmetric_plans_cover_every_tile_pair_once(monkeypatch, n, is_f64, worl
     assert np.all(steps[np.tril_indices(T, -1)] == 0)
     # snake dealing: equal pair work per rank to within one super-row
     assert max(pairs_of_rank) - min(pairs_of_rank) <= 4 * T * 64
+
+
+@pytest.mark.parametrize("split", [3, 5, 7, 11, 16])
+def test_sweep_pieces_need_not_divide_64(monkeypatch, split):
+    """NB_SYM_SPLIT = any 1 ... 16: the pieces of a sweep are [64 q / nsp, 64 (q + 1) / nsp) -- together all 64 rotation
+    steps of every work item, lengths differing by at most one."""
+    monkeypatch.setenv("NB_SYM_SPLIT", str(split))
+    p = _plan(8192, 2, 0, 1, is_f64=True)
+    assert p["enabled"] and p["nwork"] % split == 0
+    by_item = {}
+    for ti, jb, je, slot, stride, col, sb, sc in p["work"]:
+        by_item.setdefault((int(ti), int(jb), int(je)), []).append((int(sb), int(sc)))
+    for pieces in by_item.values():
+        pieces.sort()
+        assert len(pieces) == split and pieces[0][0] == 0 and pieces[-1][0] + pieces[-1][1] == 64
+        assert all(a[0] + a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+        lens = [c for _, c in pieces]
+        assert max(lens) - min(lens) <= 1
+
+
+def test_mid_size_pieces_follow_the_cost_model():
+    """fp64 mid sizes: pieces per sweep from the measured cost model of nb_plan.cpp (profiles/r03_mid_split_sweep.txt):
+    N = 5120 (60 items) 4, 6144 (84) 3 or 6, 8192 (144) 3, 10 240 (220) 2; 500 items and more keep 4."""
+    def pieces(n):
+        p = _plan(n, 2, 0, 1, is_f64=True)
+        items = {(int(w[0]), int(w[1])) for w in p["work"]}
+        return p["nwork"] // len(items)
+    assert pieces(5120) == 4 and pieces(8192) == 3 and pieces(10240) == 2
+    assert pieces(6144) in (3, 6)
+    assert pieces(16384) == 4
 
 
 def _p2p_vote_worker(rank, world, port, out):
