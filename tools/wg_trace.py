@@ -3,19 +3,24 @@
    NBODY_LIB=$PWD/nbody_cosmological_simulation_amd/libnbody_amd_wgtrace.so python tools/wg_trace.py 8192 float64
 Prints the launch's span, the workgroups per CU and the per-workgroup durations (100 MHz constant clock)."""
 import collections, ctypes as C, os, sys
-import numpy as np, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import nbody_cosmological_simulation_amd as nb
-from nbody_cosmological_simulation_amd import galaxy, _native
-n = int(sys.argv[1]); mode = sys.argv[2]
-pos, vel, m = galaxy.create_disk_galaxy(n, seed=42, device="cpu")
-sim = nb.GalaxySimulation(pos.cuda(), vel.cuda(), m.cuda(), precision_mode=nb.get_mode_from_string(mode))
-sim.run(200); sim.synchronize()
-L = _native.lib()
-f = L.nb_debug_wg_trace; f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int]
-buf = np.zeros((16384, 8), dtype=np.uint64)
-got = f(buf.ctypes.data, 16384)
-assert got > 0
+import numpy as np
+if sys.argv[1] == "--load":            # analyse a dump written earlier with DUMP=file.npy (no GPU needed)
+    buf = np.load(sys.argv[2]); n = sys.argv[2]; mode = "(dump)"; kernel = "?"
+else:
+    import torch
+    sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import nbody_cosmological_simulation_amd as nb
+    from nbody_cosmological_simulation_amd import galaxy, _native
+    n = int(sys.argv[1]); mode = sys.argv[2]
+    pos, vel, m = galaxy.create_disk_galaxy(n, seed=42, device="cpu")
+    sim = nb.GalaxySimulation(pos.cuda(), vel.cuda(), m.cuda(), precision_mode=nb.get_mode_from_string(mode))
+    sim.run(200); sim.synchronize()
+    L = _native.lib()
+    f = L.nb_debug_wg_trace; f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int]
+    buf = np.zeros((16384, 8), dtype=np.uint64)
+    got = f(buf.ctypes.data, 16384)
+    assert got > 0
+    kernel = sim.force_kernel_name()
 nz = int(np.count_nonzero(buf[:, 1]))
 b = buf[:nz].astype(np.int64)
 t0 = b[:, 0].min()
@@ -25,7 +30,7 @@ cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; simd = (hw >> 
 key = xcc * 1000 + se * 100 + sh * 20 + cu
 per = collections.Counter(key.tolist())
 dur = end - start
-print(f"N={n} {mode}: {nz} workgroups, kernel {sim.force_kernel_name()}")
+print(f"N={n} {mode}: {nz} workgroups, kernel {kernel}")
 print(f"span {end.max():.2f} us; workgroup duration min/median/mean/max {dur.min():.2f}/{np.median(dur):.2f}/{dur.mean():.2f}/{dur.max():.2f} us")
 print(f"CUs used {len(per)}; workgroups per CU histogram {sorted(collections.Counter(per.values()).items())}")
 print(f"per XCC {sorted(collections.Counter(xcc.tolist()).items())}")
@@ -55,6 +60,8 @@ for i in range(nz):
 print("waves per SIMD histogram:", sorted(collections.Counter(load.values()).items()))
 print("per-wave duration min/median/max:", wdur.min(), np.median(wdur), wdur.max())
 cyc = b[:, 3].astype(float)
-print("shader clock (cycles / us) over the workgroups: min/median/max", np.round([np.min(cyc / dur), np.median(cyc / dur), np.max(cyc / dur)], 1).tolist())
+if cyc.max() > 0: print("shader clock (cycles / us) over the workgroups: min/median/max", np.round([np.min(cyc / dur), np.median(cyc / dur), np.max(cyc / dur)], 1).tolist())
 if os.environ.get("DUMP"):
     np.save(os.environ["DUMP"], buf[:nz])
+ts = np.linspace(0, end.max(), 24, endpoint=False)
+print("resident workgroups at", round(float(ts[1]), 1), "us intervals:", [int(((start <= t) & (end > t)).sum()) for t in ts])
