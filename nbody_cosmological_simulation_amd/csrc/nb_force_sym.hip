@@ -74,7 +74,10 @@ pack_kernel(T *__restrict__ pos, T *__restrict__ vel, const T *__restrict__ acc,
 // (item c to wave c mod 16, four independent loads in flight per lane), the 16 partial sums are
 // combined in wave order through LDS -> one fixed summation tree.  Optionally fuses the closing half
 // kick (simulation.py:141) and applies the uniform-mass factor.
-constexpr int NB_RED_WAVES = 16;
+#ifndef NB_RED_WAVES_N
+#define NB_RED_WAVES_N 16
+#endif
+constexpr int NB_RED_WAVES = NB_RED_WAVES_N;
 template <typename T, int D>
 __global__ void __launch_bounds__(64 * NB_RED_WAVES)
 reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ colslab,

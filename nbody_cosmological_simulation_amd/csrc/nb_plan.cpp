@@ -169,9 +169,11 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
         // with 1 / 2 / 4 / 8 pieces; N = 2048, 144 items: no gain).
         const int pieces = items < 24 ? 8 : (items <= 64 ? 4 : 2);
         for (int S = 0; S < SR; ++S) split_of[S] = pieces;
-    } else if (sp.r == 2 && !is_f64 && items < 400) {
+    } else if (sp.r == 2 && !is_f64 && items < (in.mode >= NB_INT8_SIM ? 900 : 400)) {
         // fp32, R = 2, a few hundred items: two pieces (us per step 1 / 2 / 4 pieces: N = 4096 15.9 / 13.8 / 14.7,
-        // 6144 20.2 / 18.6 / 21.6; 8192 (544 items) 26.3 / 26.1 / 30.8)
+        // 6144 20.2 / 18.6 / 21.6; 8192 (544 items) 26.3 / 26.1 / 30.8).  The grid modes' pair loop is ~1.6 x as long, so
+        // halves pay up to more items (INT8 us per step, 1 / 2 pieces: N = 7168 (420 items) 48.3 / 45.6, 8192 (544) 54.8 /
+        // 50.6, 10 240 (840) 62.6 / 60.0, 11 264 (1012) 63.6 / 65.2; profiles/r03_tail_pieces_sweep.txt)
         for (int S = 0; S < SR; ++S) split_of[S] = 2;
     } else if (items > wg_slots / 2) {
         long long rem = items % wg_slots;
