@@ -85,6 +85,12 @@ typedef struct nb_config {
 int nb_create(nb_sim **out, const nb_config *cfg);
 int nb_destroy(nb_sim *s);
 
+/* Handles keep their stream and (up to 64 MiB) device allocation in a bounded process-level cache when they are
+ * destroyed, for the next handle on the same device: the reference's scripts build many short simulations
+ * (simulation.py:199-250 run_comparison builds one per mode; main.py:140-176 one per requested mode), and hipFree / hipStreamDestroy wait for the whole device.  nb_cache_trim releases
+ * everything the cache holds (bytes of device memory returned through released_bytes, may be NULL). */
+int nb_cache_trim(int64_t *released_bytes);
+
 /* attribute writes `sim.G = ..`, `sim.dt = ..`, `sim.softening_sq = ..` between steps
  * (crash_point_test.py, falsification_tests.py read/write them; simulation.py reads them
  * at every use :86,:101,:132-141). */

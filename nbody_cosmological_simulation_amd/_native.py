@@ -25,7 +25,7 @@ MODE_CODES = {
 
 # every symbol include/nbody_amd.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTS = [
-    "nb_create", "nb_destroy", "nb_set_params", "nb_set_state", "nb_get_state", "nb_state_dtypes",
+    "nb_create", "nb_destroy", "nb_cache_trim", "nb_set_params", "nb_set_state", "nb_get_state", "nb_state_dtypes",
     "nb_set_accelerations", "nb_compute_accelerations", "nb_step", "nb_kick_drift", "nb_kick",
     "nb_energy", "nb_quant_debug", "nb_quant_bins_rows", "nb_quant_bin_sums", "nb_comm_info", "nb_quantize_distance_squared", "nb_quantize_force",
     "nb_grid_quantize", "nb_grid_quantize_safe", "nb_comm_unique_id", "nb_comm_init", "nb_comm_ready",
@@ -82,6 +82,7 @@ def lib():
         "nb_quant_bins_rows": ([vp, i32, i32, vp], C.c_int),
         "nb_quant_bin_sums": ([vp, i32, vp, vp, pdbl], C.c_int),
         "nb_comm_info": ([pi32], C.c_int),
+        "nb_cache_trim": ([C.POINTER(C.c_int64)], C.c_int),
         "nb_quantize_distance_squared": ([C.c_int, vp, vp, i64, C.c_int, C.c_int, C.c_int, dbl, C.c_int, pi32], C.c_int),
         "nb_quantize_force": ([C.c_int, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, pi32], C.c_int),
         "nb_grid_quantize": ([C.c_int, vp, vp, i64, C.c_int, C.c_int, C.c_int], C.c_int),

@@ -62,39 +62,100 @@ using namespace nbhost;
 
 namespace {
 
-// Work list of the pair-symmetric kernel: planned on the host (nb_plan.cpp, device-free and testable on its
-// own through nb_plan_debug), mirrored here into device buffers.
-int build_sym_plan(nb_sim *s)
+// All device buffers a handle needs from its first upload on come out of ONE allocation (the reference's scripts build
+// many short simulations: with ~20 hipMalloc / hipFree pairs, constructing and closing a handle cost 0.36 + 0.30 ms
+// against the 1.0 ms of a whole 200-tick run at N = 1024; tools/create_timing.py).  Buffers that only some call
+// sequences need (metrics, generic kernel, small-system ping-pong, bin read-out, multi-GPU sums) stay lazy allocations
+// of their own.
+struct ArenaRequest { void **target; size_t bytes; };
+
+// Streams and small arenas of closed handles are kept for the next handle of the same device (process-level, bounded:
+// arenas up to 64 MiB each, 256 MiB / 16 entries in total): hipFree and hipStreamDestroy wait for the whole device and
+// cost ~0.1 ms apiece, hipMalloc / hipStreamCreate about as much.  nb_cache_trim() releases everything; NB_NO_CACHE=1
+// turns the cache off.  A reused arena is cleared before use.
+struct HandleCache {
+    static constexpr int MAX_DEV = 64;
+    static constexpr size_t MAX_ARENA = (size_t)64 << 20, MAX_TOTAL = (size_t)256 << 20, MAX_ENTRIES = 16;
+    struct Arena { void *p; size_t bytes; };
+    std::mutex mu;
+    std::vector<hipStream_t> streams[MAX_DEV];
+    std::vector<Arena> arenas[MAX_DEV];
+    int cus[MAX_DEV] = {0};
+    size_t total = 0, entries = 0;
+    bool off = getenv("NB_NO_CACHE") != nullptr;
+};
+HandleCache g_cache;
+
+int device_cus(int device)
 {
-    auto &sp = s->sym;
-    sp.enabled = false;
-    const nb_config &c = s->cfg;
-    PlanInput in;
-    in.n = c.n; in.dim = c.dim; in.mode = c.mode; in.flags = c.flags; in.rank = c.rank; in.nranks = c.nranks;
-    in.is_f64 = s->is_f64;
-    in.multi = comm_active(s);
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) in.cus = prop.multiProcessorCount; }
-    SymPlanHost h;
-    nb_plan_sym(in, s->knobs, h);
-    if (!h.enabled) return NB_OK;
-    sp.r = h.r; sp.tile_b = h.tile_b; sp.tiles = h.tiles; sp.np = h.np;
-    sp.nwork = (int)h.work.size();
-    sp.nslots = h.nslots;
-    HIPCHK(hipMalloc((void **)&sp.work, h.work.size() * sizeof(SymWork)));
-    HIPCHK(hipMalloc((void **)&sp.row_slot0, sp.tiles * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&sp.row_nslots, sp.tiles * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&sp.col_upto, sp.tiles * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&sp.packed, h.packed_bytes));
-    HIPCHK(hipMalloc((void **)&sp.rowslab, h.row_bytes));
-    HIPCHK(hipMalloc((void **)&sp.colslab, h.col_bytes));
-    HIPCHK(hipMemcpy(sp.work, h.work.data(), h.work.size() * sizeof(SymWork), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp.row_slot0, h.row_slot0.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp.row_nslots, h.row_nslots.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp.col_upto, h.col_upto.data(), sp.tiles * sizeof(int), hipMemcpyHostToDevice));
-    sp.enabled = true;
-    return NB_OK;
+    if (device < 0 || device >= HandleCache::MAX_DEV) return 256;
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    if (!g_cache.cus[device]) {
+        hipDeviceProp_t prop;       // (slow call: once per device and process)
+        g_cache.cus[device] = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    return g_cache.cus[device];
 }
 
+hipError_t arena_acquire(int device, size_t bytes, void **out, size_t *got, bool *reused)
+{
+    *reused = false;
+    if (!g_cache.off && device >= 0 && device < HandleCache::MAX_DEV) {
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        auto &v = g_cache.arenas[device];
+        int best = -1;
+        for (int i = 0; i < (int)v.size(); ++i)
+            if (v[i].bytes >= bytes && v[i].bytes <= 2 * bytes + ((size_t)1 << 20) && (best < 0 || v[i].bytes < v[best].bytes)) best = i;
+        if (best >= 0) {
+            *out = v[best].p; *got = v[best].bytes;
+            g_cache.total -= v[best].bytes; g_cache.entries--;
+            v.erase(v.begin() + best);
+            *reused = true;
+            return hipSuccess;
+        }
+    }
+    *got = bytes;
+    return hipMalloc(out, bytes);
+}
+
+void arena_release(int device, void *p, size_t bytes)
+{
+    if (!p) return;
+    if (!g_cache.off && device >= 0 && device < HandleCache::MAX_DEV && bytes <= HandleCache::MAX_ARENA) {
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        if (g_cache.total + bytes <= HandleCache::MAX_TOTAL && g_cache.entries < HandleCache::MAX_ENTRIES) {
+            g_cache.arenas[device].push_back({p, bytes});
+            g_cache.total += bytes; g_cache.entries++;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+hipError_t stream_acquire(int device, hipStream_t *out)
+{
+    if (!g_cache.off && device >= 0 && device < HandleCache::MAX_DEV) {
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        auto &v = g_cache.streams[device];
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void stream_release(int device, hipStream_t st)       // `st` is idle (the caller synchronised it)
+{
+    if (!st) return;
+    if (!g_cache.off && device >= 0 && device < HandleCache::MAX_DEV) {
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        if (g_cache.streams[device].size() < 8) { g_cache.streams[device].push_back(st); return; }
+    }
+    (void)hipStreamDestroy(st);
+}
+constexpr size_t ARENA_ALIGN = 256;
+inline size_t arena_round(size_t b) { return (b + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN; }
+
+// Storage of a handle + the work list of the pair-symmetric kernel (planned on the host: nb_plan.cpp, device-free and
+// testable on its own through nb_plan_debug; mirrored here into device buffers).
 int ensure_storage(nb_sim *s, bool f64)
 {
     if (s->have_storage) {
@@ -105,44 +166,104 @@ int ensure_storage(nb_sim *s, bool f64)
     }
     HIPCHK(hipSetDevice(s->cfg.device));
     s->is_f64 = f64;
+    const nb_config &c = s->cfg;
     const size_t el = f64 ? 8 : 4;
     const size_t cnt = (size_t)nd(s);
-    HIPCHK(hipMalloc(&s->pos, cnt * el));
-    HIPCHK(hipMalloc(&s->vel, cnt * el));
-    HIPCHK(hipMalloc(&s->acc, cnt * el));
-    HIPCHK(hipMalloc(&s->mass, (size_t)s->cfg.n * el));
-    HIPCHK(hipMalloc(&s->staging, cnt * 8));
-    HIPCHK(hipMalloc((void **)&s->partial, (size_t)s->geom.nchunks * cnt * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&s->tab, sizeof(GridTables)));
-    HIPCHK(hipMemsetAsync(s->tab, 0, sizeof(GridTables), s->stream));
-    const size_t pe_blocks = (size_t)((s->cfg.n + NB_BLOCK - 1) / NB_BLOCK) * s->geom.nchunks;
-    s->scratch_elems = std::max<size_t>(pe_blocks, 1024);
-    HIPCHK(hipMalloc((void **)&s->scratch, s->scratch_elems * sizeof(double)));
-    // scalars[0..7] results, [8 ...] partials of the two-stage min/max
-    HIPCHK(hipMalloc((void **)&s->scalars, (8 + 2 * NB_MINMAX_BLOCKS) * sizeof(double)));
-    HIPCHK(hipMemsetAsync(s->scalars, 0, (8 + 2 * NB_MINMAX_BLOCKS) * sizeof(double), s->stream));
-    if (force_quant_mode(s->cfg)) HIPCHK(hipMalloc((void **)&s->fbins, cnt * sizeof(int16_t)));
-    if (!f64 && grid_mode(s->cfg.mode)) {
-        HIPCHK(hipMalloc((void **)&s->prune_cand, cnt * sizeof(float)));
-        HIPCHK(hipMalloc((void **)&s->prune_rho, (size_t)s->cfg.n * sizeof(float)));
-        HIPCHK(hipMalloc((void **)&s->prune_idx, (size_t)s->cfg.n * sizeof(int)));
-        HIPCHK(hipMalloc((void **)&s->prune_state, sizeof(PruneState)));
-        PruneState init{};
-        for (int k = 0; k < 3; ++k) { init.box_min[k] = 0xffffffffu; init.box_max[k] = 0u; }
-        HIPCHK(hipMemcpy(s->prune_state, &init, sizeof init, hipMemcpyHostToDevice));
+
+    // ---- the plan first: its sizes are part of the allocation ----------------------------------------------------
+    auto &sp = s->sym;
+    sp.enabled = false;
+    PlanInput in;
+    in.n = c.n; in.dim = c.dim; in.mode = c.mode; in.flags = c.flags; in.rank = c.rank; in.nranks = c.nranks;
+    in.is_f64 = s->is_f64;
+    in.multi = comm_active(s);
+    in.cus = device_cus(c.device);
+    SymPlanHost h;
+    nb_plan_sym(in, s->knobs, h);
+    if (h.enabled) {
+        sp.r = h.r; sp.tile_b = h.tile_b; sp.tiles = h.tiles; sp.np = h.np;
+        sp.nwork = (int)h.work.size();
+        sp.nslots = h.nslots;
     }
-    HIPCHK(hipMemsetAsync(s->acc, 0, cnt * el, s->stream));
-    if (int rc = build_sym_plan(s)) return rc;
-    if ((size_t)s->sym.nwork > s->scratch_elems) {
-        (void)hipFree(s->scratch);
-        s->scratch_elems = (size_t)s->sym.nwork;
-        HIPCHK(hipMalloc((void **)&s->scratch, s->scratch_elems * sizeof(double)));
+    const size_t pe_blocks = (size_t)((c.n + NB_BLOCK - 1) / NB_BLOCK) * s->geom.nchunks;
+    s->scratch_elems = std::max<size_t>(std::max<size_t>(pe_blocks, 1024), h.enabled ? h.work.size() : 0);
+    const bool prune = !f64 && grid_mode(c.mode);
+
+    // ---- one allocation ---------------------------------------------------------------------------------------------
+    // zero-initialised block first (tab, scalars, acc: one memset), then the block initialised from the host (plan
+    // tables, prune state: one copy), then everything else
+    void *plan_blob = nullptr;
+    const size_t plan_ints = h.enabled ? (size_t)sp.tiles * 3 : 0;
+    const size_t plan_bytes = h.enabled ? arena_round(h.work.size() * sizeof(SymWork)) + arena_round(plan_ints * sizeof(int)) : 0;
+    const size_t blob_bytes = plan_bytes + (prune ? arena_round(sizeof(PruneState)) : 0);
+    const size_t scalars_bytes = (8 + 2 * NB_MINMAX_BLOCKS) * sizeof(double);   // [0..7] results, [8 ...] partials of the two-stage min/max
+    std::vector<ArenaRequest> req = {
+        {(void **)&s->tab, sizeof(GridTables)}, {(void **)&s->scalars, scalars_bytes}, {&s->acc, cnt * el},
+        {&plan_blob, blob_bytes},
+        {&s->pos, cnt * el}, {&s->vel, cnt * el}, {&s->mass, (size_t)c.n * el}, {&s->staging, cnt * 8},
+        {(void **)&s->partial, (size_t)s->geom.nchunks * cnt * sizeof(double)},
+        {(void **)&s->scratch, s->scratch_elems * sizeof(double)},
+    };
+    if (force_quant_mode(c)) req.push_back({(void **)&s->fbins, cnt * sizeof(int16_t)});
+    if (prune) {
+        req.push_back({(void **)&s->prune_cand, cnt * sizeof(float)});
+        req.push_back({(void **)&s->prune_rho, (size_t)c.n * sizeof(float)});
+        req.push_back({(void **)&s->prune_idx, (size_t)c.n * sizeof(int)});
     }
+    if (h.enabled) {
+        req.push_back({&sp.packed, h.packed_bytes});
+        req.push_back({(void **)&sp.rowslab, h.row_bytes});
+        req.push_back({&sp.colslab, h.col_bytes});
+    }
+    size_t total = 0;
+    for (const ArenaRequest &r : req) total += arena_round(r.bytes);
+    bool reused = false;
+    HIPCHK(arena_acquire(c.device, std::max<size_t>(total, ARENA_ALIGN), &s->arena, &s->arena_bytes, &reused));
+    size_t off = 0;
+    for (const ArenaRequest &r : req) {
+        *r.target = r.bytes ? (void *)((char *)s->arena + off) : nullptr;
+        off += arena_round(r.bytes);
+    }
+    const size_t zero_bytes = arena_round(sizeof(GridTables)) + arena_round(scalars_bytes) + arena_round(cnt * el);
+    // a reused arena (<= 64 MiB) is cleared as a whole: every buffer starts from zeros, as on freshly mapped memory --
+    // except the host-initialised block, which the synchronous copy below fills (this memset is asynchronous on the
+    // handle's non-blocking stream and must not touch what that copy writes)
+    HIPCHK(hipMemsetAsync(s->arena, 0, zero_bytes, s->stream));
+    if (reused) {
+        const size_t rest = zero_bytes + arena_round(blob_bytes);
+        if (s->arena_bytes > rest) HIPCHK(hipMemsetAsync((char *)s->arena + rest, 0, s->arena_bytes - rest, s->stream));
+    }
+    if (blob_bytes) {
+        std::vector<char> host(blob_bytes, 0);
+        size_t o = 0;
+        if (h.enabled) {
+            sp.work = (SymWork *)((char *)plan_blob + o);
+            std::memcpy(host.data() + o, h.work.data(), h.work.size() * sizeof(SymWork));
+            o += arena_round(h.work.size() * sizeof(SymWork));
+            int *ints = (int *)((char *)plan_blob + o);
+            sp.row_slot0 = ints; sp.row_nslots = ints + sp.tiles; sp.col_upto = ints + 2 * (size_t)sp.tiles;
+            std::memcpy(host.data() + o, h.row_slot0.data(), sp.tiles * sizeof(int));
+            std::memcpy(host.data() + o + sp.tiles * sizeof(int), h.row_nslots.data(), sp.tiles * sizeof(int));
+            std::memcpy(host.data() + o + 2 * (size_t)sp.tiles * sizeof(int), h.col_upto.data(), sp.tiles * sizeof(int));
+            o += arena_round(plan_ints * sizeof(int));
+        }
+        if (prune) {
+            s->prune_state = (PruneState *)((char *)plan_blob + o);
+            PruneState init{};
+            for (int k = 0; k < 3; ++k) { init.box_min[k] = 0xffffffffu; init.box_max[k] = 0u; }
+            std::memcpy(host.data() + o, &init, sizeof init);
+        }
+        HIPCHK(hipMemcpy(plan_blob, host.data(), blob_bytes, hipMemcpyHostToDevice));
+    }
+    sp.enabled = h.enabled;
     s->have_storage = true;
     return NB_OK;
 }
 
-// copy `count` elements of dtype `dt` from a caller buffer into state storage (with conversion)
+// copy `count` elements of dtype `dt` from a caller buffer into state storage (with conversion), asynchronously on the
+// handle's stream.  The caller owns `src` and may free or overwrite it as soon as the ENTRY POINT returns (a torch
+// temporary goes back to the caching allocator): every entry point that uploads ends with ONE hipStreamSynchronize
+// (three arrays used to cost three).  The staging buffer is reused by the next array in stream order.
 int upload(nb_sim *s, const void *src, int dt, int on_device, void *dst, int64_t count)
 {
     const int sdt = s->is_f64 ? NB_F64 : NB_F32;
@@ -150,19 +271,14 @@ int upload(nb_sim *s, const void *src, int dt, int on_device, void *dst, int64_t
     if (dt == sdt) {
         HIPCHK(hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                               s->stream));
-        // the caller owns `src` and may free or overwrite it as soon as we return (a torch temporary
-        // goes back to the caching allocator): the copy must have consumed it by then
-        HIPCHK(hipStreamSynchronize(s->stream));
         return NB_OK;
     }
     const void *dsrc = src;
     if (!on_device) {
         HIPCHK(hipMemcpyAsync(s->staging, src, bytes, hipMemcpyHostToDevice, s->stream));
-        HIPCHK(hipStreamSynchronize(s->stream));
         dsrc = s->staging;
     }
     HIPCHK(nb_launch_convert(dsrc, dt, dst, sdt, count, s->stream));
-    if (on_device) HIPCHK(hipStreamSynchronize(s->stream));        // same ownership rule as above
     return NB_OK;
 }
 
@@ -223,7 +339,7 @@ int nb_create(nb_sim **out, const nb_config *cfg)
     s->cfg = *cfg;
     s->knobs = nb_read_knobs();
     DeviceGuard guard(cfg->device);
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (stream_acquire(cfg->device, &s->stream) != hipSuccess) {
         delete s;
         return fail(NB_ERR_HIP, "hipStreamCreate failed");
     }
@@ -248,11 +364,29 @@ int nb_destroy(nb_sim *s)
                     (void *)s->sym.packed, (void *)s->sym.rowslab, (void *)s->sym.colslab,
                     (void *)s->prune_cand, (void *)s->prune_rho, (void *)s->prune_idx, (void *)s->prune_state, s->metrics_scratch, s->gen_scalars, s->pos_alt, (void *)s->small_part,
                     (void *)s->sums64, (void *)s->bin_out})
-        if (p) (void)hipFree(p);
+        if (p && !(s->arena && (char *)p >= (char *)s->arena && (char *)p < (char *)s->arena + s->arena_bytes)) (void)hipFree(p);
+    arena_release(s->cfg.device, s->arena, s->arena_bytes);
     if (s->prof_init)
         for (int i = 0; i < PROF_RING; ++i) { (void)hipEventDestroy(s->ev_start[i]); (void)hipEventDestroy(s->ev_stop[i]); }
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    stream_release(s->cfg.device, s->stream);
     delete s;
+    return NB_OK;
+}
+
+int nb_cache_trim(int64_t *released_bytes)
+{
+    size_t freed = 0;
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    for (int d = 0; d < HandleCache::MAX_DEV; ++d) {
+        if (g_cache.arenas[d].empty() && g_cache.streams[d].empty()) continue;
+        DeviceGuard guard(d);
+        for (auto &a : g_cache.arenas[d]) { (void)hipFree(a.p); freed += a.bytes; }
+        for (hipStream_t st : g_cache.streams[d]) (void)hipStreamDestroy(st);
+        g_cache.arenas[d].clear();
+        g_cache.streams[d].clear();
+    }
+    g_cache.total = 0; g_cache.entries = 0;
+    if (released_bytes) *released_bytes = (int64_t)freed;
     return NB_OK;
 }
 
@@ -294,6 +428,8 @@ int nb_set_state(nb_sim *s, const void *pos, const void *vel, const void *mass, 
         HIPCHK(hipStreamSynchronize(s->stream));
         s->mass_uniform = (mm[0] == mm[1]) && std::isfinite(mm[0]) && !s->knobs.no_uniform;
         s->mass_value = mm[0];
+    } else {
+        HIPCHK(hipStreamSynchronize(s->stream));      // the copies have consumed the caller's buffers
     }
     return NB_OK;
 }
@@ -306,6 +442,7 @@ int nb_set_accelerations(nb_sim *s, const void *acc, int dtype, int on_device)
     if (dtype == NB_F64 && !s->is_f64) return fail(NB_ERR_UNSUPPORTED, "fp64 accelerations on fp32 state");
     DeviceGuard guard(s->cfg.device);
     if (int rc = upload(s, acc, dtype, on_device, s->acc, nd(s))) return rc;
+    HIPCHK(hipStreamSynchronize(s->stream));
     s->logical[3] = dtype;
     s->have_acc = true;
     return NB_OK;

@@ -111,6 +111,8 @@ struct nb_sim {
     bool is_f64 = false;                 // storage / accumulation type of the state buffers
     int logical[4] = {NB_F32, NB_F32, NB_F32, NB_F32};   // pos, vel, mass, acc as Python sees them
     bool have_pos = false, have_vel = false, have_mass = false, have_acc = false;
+    void *arena = nullptr;               // ONE device allocation behind the buffers of the first upload (nb_api.cpp: ensure_storage)
+    size_t arena_bytes = 0;
     void *pos = nullptr, *vel = nullptr, *mass = nullptr, *acc = nullptr;
     double *partial = nullptr;           // nchunks slabs of n*dim fp64 partial sums
     void *staging = nullptr;             // n*dim*8 bytes, for dtype conversion on upload / download

@@ -195,6 +195,14 @@ def shutdown():
     N.check(L.nb_comm_shutdown())
 
 
+def trim_cache() -> int:
+    """Release the streams and device allocations that closed simulations left in the library's bounded cache
+    (include/nbody_amd.h: nb_cache_trim); returns the bytes of device memory given back."""
+    freed = C.c_int64(0)
+    N.check(N.lib().nb_cache_trim(C.byref(freed)))
+    return int(freed.value)
+
+
 def rank_world():
     return _ctx["rank"], _ctx["world"]
 

@@ -102,9 +102,7 @@ class GalaxySimulation:
             runtime.attach_communicator(self._handle)      # one communicator per process, shared
 
         # simulation.py:63-65: clone -> device.  The clone is the upload itself.
-        self._upload("positions", positions)
-        self._upload("velocities", velocities)
-        self._upload("masses", masses)
+        self._upload_initial(positions, velocities, masses)
 
         # simulation.py:69 (virtual call: subclasses may override _compute_accelerations)
         self.accelerations = self._compute_accelerations()
@@ -147,6 +145,27 @@ class GalaxySimulation:
 
     def __del__(self):
         self.close()
+
+    def _upload_initial(self, positions, velocities, masses):
+        """The three initial arrays: ONE native call (one stream synchronisation) when they share dtype and residence --
+        what every script of the reference passes -- else array by array."""
+        ts = [t.detach() for t in (positions, velocities, masses)]
+        same = (len({t.dtype for t in ts}) == 1 and len({t.device.type for t in ts}) == 1 and ts[0].dtype in _TORCH_TO_NB
+                and tuple(ts[1].shape) == tuple(ts[0].shape) == (self.num_stars, self._cfg_dim)
+                and tuple(ts[2].shape) == (self.num_stars,))
+        if not same:
+            self._upload("positions", positions)
+            self._upload("velocities", velocities)
+            self._upload("masses", masses)
+            return
+        self._serial += 1
+        ts = [t.contiguous() for t in ts]
+        on_device = ts[0].device.type == "cuda"
+        if on_device:
+            for dev in {t.device for t in ts}:
+                torch.cuda.current_stream(dev).synchronize()
+        N.check(N.lib().nb_set_state(self._handle, C.c_void_p(ts[0].data_ptr()), C.c_void_p(ts[1].data_ptr()),
+                                     C.c_void_p(ts[2].data_ptr()), _TORCH_TO_NB[ts[0].dtype], int(on_device)))
 
     def _upload(self, name, tensor):
         self._serial += 1

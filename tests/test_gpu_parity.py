@@ -2298,3 +2298,32 @@ def test_snapshot_round_trip_of_half_typed_state_at_tick_zero(nb, tmp_path, dtyp
     sim.run(3)
     back.run(3)
     assert torch.equal(sim.positions, back.positions) and torch.equal(sim.velocities, back.velocities)
+
+
+@pytest.mark.gpu
+def test_handle_cache_reuse_is_invisible(nb):
+    """Closed handles leave their stream and device allocation in the library's bounded cache (nb_cache_trim): a
+    simulation built on a reused allocation -- stale contents of a DIFFERENT mode and size -- must give bit-identical
+    results to one built on fresh memory, and the trim must hand the memory back."""
+    from nbody_cosmological_simulation_amd import galaxy, runtime
+    runtime.trim_cache()
+    pos, vel, mass = galaxy.create_disk_galaxy(1500, seed=5, device="cpu")
+
+    def run(mode):
+        sim = nb.GalaxySimulation(pos, vel, mass, precision_mode=mode)
+        sim.run(20)
+        out = (sim.positions.clone(), sim.velocities.clone(), sim.get_total_energy())
+        sim.close()
+        return out
+
+    fresh = {m: run(m) for m in (nb.PrecisionMode.FLOAT64, nb.PrecisionMode.INT8_SIM, nb.PrecisionMode.FLOAT32)}
+    assert runtime.trim_cache() > 0 and runtime.trim_cache() == 0
+    # fill the cache with an allocation full of other data, then rerun every mode on reused memory
+    p2, v2, m2 = galaxy.create_disk_galaxy(2500, seed=9, device="cpu")
+    other = nb.GalaxySimulation(p2 * 3, v2, m2, precision_mode=nb.PrecisionMode.INT4_SIM)
+    other.run(5)
+    other.close()
+    for m, (x0, v0, e0) in fresh.items():
+        x1, v1, e1 = run(m)
+        assert torch.equal(x0, x1) and torch.equal(v0, v1) and e0 == e1, m
+    assert runtime.trim_cache() > 0
