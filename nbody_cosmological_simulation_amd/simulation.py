@@ -204,6 +204,23 @@ class GalaxySimulation:
         N.check(N.lib().nb_get_state(self._handle, args[0], args[1], args[2], args[3], int(on_device)))
         return out
 
+    def _prefetch(self, names):
+        """Download every array of `names` that is not cached yet in ONE native call (one stream synchronisation
+        instead of one per array: get_state reads three)."""
+        missing = [n for n in names if n not in self._cache]
+        if len(missing) < 2 or self._empty:
+            return
+        dts = (C.c_int32 * 4)()
+        N.check(N.lib().nb_state_dtypes(self._handle, dts))
+        outs, args = {}, [None, None, None, None]
+        for n in missing:
+            shape = (self.num_stars,) if n == "masses" else (self.num_stars, self._dim())
+            outs[n] = torch.empty(shape, dtype=_NB_TO_TORCH[dts[_IDX[n]]], device=self.device)
+            args[{"positions": 0, "velocities": 1, "accelerations": 2, "masses": 3}[n]] = C.c_void_p(outs[n].data_ptr())
+        N.check(N.lib().nb_get_state(self._handle, args[0], args[1], args[2], args[3], int(self.device.type == "cuda")))
+        for n, t in outs.items():
+            self._cache[n] = [t, t._version, False]
+
     def _dim(self):
         return self._cfg_dim
 
@@ -243,8 +260,11 @@ class GalaxySimulation:
             if dirty or t._version != ver:
                 self._upload(name, t)
                 ent[1], ent[2] = t._version, False
-        # attribute writes such as `sim.dt = 0.02` (simulation.py reads them at every use)
-        N.check(N.lib().nb_set_params(self._handle, float(self.G), float(self.softening_sq), float(self.dt)))
+        # attribute writes such as `sim.dt = 0.02` (simulation.py reads them at every use): pushed down when they change
+        params = (float(self.G), float(self.softening_sq), float(self.dt))
+        if params != getattr(self, "_params_sent", None):
+            N.check(N.lib().nb_set_params(self._handle, *params))
+            self._params_sent = params
 
     def _invalidate(self, *names):
         self._serial += 1
@@ -320,6 +340,8 @@ class GalaxySimulation:
 
     def get_state(self) -> dict:
         """Current state as clones (reference simulation.py:160-168)."""
+        if not self._empty:
+            self._prefetch(("positions", "velocities", "masses"))
         return {
             "positions": self.positions.clone(),
             "velocities": self.velocities.clone(),
