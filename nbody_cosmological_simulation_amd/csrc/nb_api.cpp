@@ -184,6 +184,7 @@ int ensure_storage(nb_sim *s, bool f64)
         sp.r = h.r; sp.tile_b = h.tile_b; sp.tiles = h.tiles; sp.np = h.np;
         sp.nwork = (int)h.work.size();
         sp.nslots = h.nslots;
+        sp.rowsplit = h.rowsplit > 0;
     }
     const size_t pe_blocks = (size_t)((c.n + NB_BLOCK - 1) / NB_BLOCK) * s->geom.nchunks;
     s->scratch_elems = std::max<size_t>(std::max<size_t>(pe_blocks, 1024), h.enabled ? h.work.size() : 0);

@@ -297,8 +297,12 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
     constexpr int B = 64 * R;
     __shared__ double s_red[NB_BLOCK / 64];
     const SymWork wk = work[blockIdx.x];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int I = wk.tile_i + wave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR
+    // row-split work items (see force_sym_kernel): one target tile, the rotation steps shared among the four waves
+    const bool rowsplit = wk.slot_stride < 0;
+    const int I = wk.tile_i + (rowsplit ? 0 : wave);
+    const int wk_s_begin = rowsplit ? wk.s_begin + wk.s_count * wave / (NB_BLOCK / 64) : wk.s_begin;
+    const int wk_s_count = rowsplit ? wk.s_begin + wk.s_count * (wave + 1) / (NB_BLOCK / 64) - wk_s_begin : wk.s_count;
     const int rot_addr = ((lane + 1) & 63) << 2;
     using TA = std::conditional_t<F32T, float, T>;      // arithmetic type of the pair terms
 
@@ -317,18 +321,18 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
             f2 xj2[R / 2][D], mj2[R / 2];
 #pragma unroll
             for (int h = 0; h < R / 2; ++h) {
-                const int p0 = J * B + 2 * h * 64 + ((lane + wk.s_begin) & 63);
+                const int p0 = J * B + 2 * h * 64 + ((lane + wk_s_begin) & 63);
 #pragma unroll
                 for (int k = 0; k < D; ++k) xj2[h][k] = f2{(float)packed[(size_t)k * np + p0], (float)packed[(size_t)k * np + p0 + 64]};
                 mj2[h] = UNIFORM ? f2{1.0f, 1.0f} : f2{(float)packed[(size_t)D * np + p0], (float)packed[(size_t)D * np + p0 + 64]};
             }
-            sum += diag ? pe_sweep_f32<D, R, true, UNIFORM>(xi, mi, xj2, mj2, eps2_f, mass_dt, rot_addr, wk.s_begin, wk.s_count)
-                        : pe_sweep_f32<D, R, false, UNIFORM>(xi, mi, xj2, mj2, eps2_f, mass_dt, rot_addr, wk.s_begin, wk.s_count);
+            sum += diag ? pe_sweep_f32<D, R, true, UNIFORM>(xi, mi, xj2, mj2, eps2_f, mass_dt, rot_addr, wk_s_begin, wk_s_count)
+                        : pe_sweep_f32<D, R, false, UNIFORM>(xi, mi, xj2, mj2, eps2_f, mass_dt, rot_addr, wk_s_begin, wk_s_count);
         } else {
             T xj[R][D], mj[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int p = J * B + r * 64 + ((lane + wk.s_begin) & 63);
+                const int p = J * B + r * 64 + ((lane + wk_s_begin) & 63);
 #pragma unroll
                 for (int k = 0; k < D; ++k) xj[r][k] = packed[(size_t)k * np + p];
                 mj[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
@@ -337,11 +341,11 @@ potential_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ w
                 float mif[R], mjf[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) { mif[r] = (float)mi[r]; mjf[r] = (float)mj[r]; }
-                sum += diag ? pe_sweep_f64<T, float, D, R, true, UNIFORM>(xi, mif, xj, mjf, eps2, mass_dt, rot_addr, wk.s_begin, wk.s_count)
-                            : pe_sweep_f64<T, float, D, R, false, UNIFORM>(xi, mif, xj, mjf, eps2, mass_dt, rot_addr, wk.s_begin, wk.s_count);
+                sum += diag ? pe_sweep_f64<T, float, D, R, true, UNIFORM>(xi, mif, xj, mjf, eps2, mass_dt, rot_addr, wk_s_begin, wk_s_count)
+                            : pe_sweep_f64<T, float, D, R, false, UNIFORM>(xi, mif, xj, mjf, eps2, mass_dt, rot_addr, wk_s_begin, wk_s_count);
             } else {
-                sum += diag ? pe_sweep_f64<T, T, D, R, true, UNIFORM>(xi, mi, xj, mj, eps2, mass_dt, rot_addr, wk.s_begin, wk.s_count)
-                            : pe_sweep_f64<T, T, D, R, false, UNIFORM>(xi, mi, xj, mj, eps2, mass_dt, rot_addr, wk.s_begin, wk.s_count);
+                sum += diag ? pe_sweep_f64<T, T, D, R, true, UNIFORM>(xi, mi, xj, mj, eps2, mass_dt, rot_addr, wk_s_begin, wk_s_count)
+                            : pe_sweep_f64<T, T, D, R, false, UNIFORM>(xi, mi, xj, mj, eps2, mass_dt, rot_addr, wk_s_begin, wk_s_count);
             }
         }
     }
@@ -384,8 +388,13 @@ hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mas
 
 hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, int nwork, double *rowslab,
                                    double *colslab, int np, int dim, int r, int uniform, int pa_f32, double eps2,
-                                   hipStream_t st, NbKernelEvents ev)
+                                   hipStream_t st, NbKernelEvents ev, int rowsplit)
 {
+    if (rowsplit) {         // row-split work items (nb_plan.cpp): their own instantiations
+        if (dim != 2 || r != 4) return hipErrorInvalidValue;
+        if (pa_f32) return launch_sym_rowsplit<HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, (float)eps2, st, ev);
+        return launch_sym_rowsplit<HOOK_NONE>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, 1.0f, st, ev);
+    }
     if (pa_f32) {   // first evaluation on fp32-typed positions: default tile shapes only
         const float e32 = (float)eps2;
         if (dim == 2 && r == 4) return launch_sym_u<double, 2, 4, HOOK_F32PAIR>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, nullptr, e32, st, ev);

@@ -454,10 +454,11 @@ __device__ unsigned long long nb_wg_trace_buf[NB_WG_TRACE_MAX][8];
 // rowslab [slot][D][B] fp64 (one target tile per workgroup slot), colslab [row][D][NP] of T.
 // <= 128 VGPRs: four waves per SIMD.  (Five waves -- 96 VGPRs -- were measured too: no gain at any
 // shard count, and the general-mass kernel starts to spill.)
+// (The general-mass row-split instantiations need 134-140 VGPRs: three waves per SIMD instead of spilling.)
 // BINS (nb_force_sym_bins.hip only): the same body with the bin read-out of BinDbg; bin_out = {s1[n], s2[n],
 // {table-free pairs, table pairs}} as unsigned 64-bit integers, added with atomics (integer sums: order-free).
-template <typename T, int D, int R, bool UNIFORM, int HOOK, int LPC = NB_LUT_MIN, bool BINS = false>
-__global__ void __launch_bounds__(NB_BLOCK, BINS ? 2 : ((HOOK == HOOK_GRID && LPC > NB_LUT_MIN) ? 3 : 4))
+template <typename T, int D, int R, bool UNIFORM, int HOOK, int LPC = NB_LUT_MIN, bool BINS = false, bool RSPLIT = false>
+__global__ void __launch_bounds__(NB_BLOCK, BINS ? 2 : ((HOOK == HOOK_GRID && LPC > NB_LUT_MIN) || (RSPLIT && !UNIFORM) ? 3 : 4))
 force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work, double *__restrict__ rowslab,
                  T *__restrict__ colslab, int np, T eps2, const GridTables *__restrict__ tab, float gfac, float g_newton,
                  unsigned long long *__restrict__ bin_out, int bin_n)
@@ -481,8 +482,19 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
     const unsigned long long trace_c0 = __builtin_readcyclecounter();
 #endif
     const SymWork wk = work[blockIdx.x];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int I = wk.tile_i + wave;             // this wave's target tile (wave-uniform)
+    // (row-split: the wave index in an SGPR, so that the per-wave step range below is scalar)
+    const int wave = RSPLIT ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // Row-split work items (RSPLIT instantiations; fp64, D = 2, R = 4 plans of mid-sized systems, nb_plan.cpp): all four
+    // waves hold the SAME target tile and share the item's rotation steps among them, so the workgroup leaves ONE row
+    // slot (the waves' row sums are added through LDS in wave order) + one column entry instead of four + one.  A
+    // separate instantiation: carried as a run-time flag the extra code cost the headline launch 0.5 % (same-box A/B
+    // 1189.2 vs 1183.5 us per step, profiles/r03_rowsplit_sweep.txt).
+    static_assert(!RSPLIT || (!std::is_same_v<T, float> && D == 2 && R == 4), "row-split: fp64, 2-D, four targets per lane");
+    constexpr bool RS_OK = RSPLIT;
+    constexpr bool rowsplit = RSPLIT;
+    const int I = wk.tile_i + (rowsplit ? 0 : wave);            // this wave's target tile (wave-uniform)
+    const int wk_s_begin = rowsplit ? wk.s_begin + wk.s_count * wave / (NB_BLOCK / 64) : wk.s_begin;
+    const int wk_s_count = rowsplit ? wk.s_begin + wk.s_count * (wave + 1) / (NB_BLOCK / 64) - wk_s_begin : wk.s_count;
     const int rot_addr = ((lane + 1) & 63) << 2;
     GridArgs ga{s_thr, s_lut, 0.0f, 0.0f, gfac, 0, lp, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     bool use_est = false, fast = false, degenerate = false;
@@ -561,7 +573,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
         if constexpr (BINS) {
 #pragma unroll
             for (int r = 0; r < RJ; ++r) {
-                bd.jp[r] = J * B + (hs + r) * 64 + ((lane + wk.s_begin) & 63);
+                bd.jp[r] = J * B + (hs + r) * 64 + ((lane + wk_s_begin) & 63);
                 bd.j1[r] = bd.j2[r] = 0;
             }
         }
@@ -576,7 +588,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
 #pragma unroll
                 for (int h = 0; h < RJ / 2; ++h) {
                     // a split sweep starts s_begin rotation steps in: lane l meets particle (l + s_begin) first
-                    const int p0 = J * B + (hs + 2 * h) * 64 + ((lane + wk.s_begin) & 63);
+                    const int p0 = J * B + (hs + 2 * h) * 64 + ((lane + wk_s_begin) & 63);
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
                         xj2[h][k] = f2{packed[(size_t)k * np + p0], packed[(size_t)k * np + p0 + 64]};
@@ -592,8 +604,8 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                     for (int k = 0; k < D; ++k) ai2[r][k] = f2{0.0f, 0.0f};
 #define NB_SWEEP_PK(EE)                                                                                                   \
     do {                                                                                                                 \
-        if (diag) sweep_pk<D, R, RJ, true, UNIFORM, HOOK, EE, BINS>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count, bd); \
-        else sweep_pk<D, R, RJ, false, UNIFORM, HOOK, EE, BINS>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk.s_count, bd);     \
+        if (diag) sweep_pk<D, R, RJ, true, UNIFORM, HOOK, EE, BINS>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk_s_count, bd); \
+        else sweep_pk<D, R, RJ, false, UNIFORM, HOOK, EE, BINS>(xi, gi, ai2, xj2, gj2, aj2, eps2, rot_addr, ga, wk_s_count, bd);     \
     } while (0)
                 if (HOOK == HOOK_GRID && fast) {
                     if (eps2 < 0.01f) NB_SWEEP_PK(GRID_FAST_CLAMP);
@@ -620,7 +632,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                 T xj[RJ][D], gj[RJ], ai[R][D];
 #pragma unroll
                 for (int r = 0; r < RJ; ++r) {
-                    const int p = J * B + (hs + r) * 64 + ((lane + wk.s_begin) & 63);
+                    const int p = J * B + (hs + r) * 64 + ((lane + wk_s_begin) & 63);
 #pragma unroll
                     for (int k = 0; k < D; ++k) xj[r][k] = packed[(size_t)k * np + p];
                     gj[r] = UNIFORM ? (T)1 : packed[(size_t)D * np + p];
@@ -632,8 +644,8 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
                     for (int k = 0; k < D; ++k) ai[r][k] = F32 ? (T)0 : (T)row_ref(r, k);
 #define NB_SWEEP(EE)                                                                                                  \
     do {                                                                                                                 \
-        if (diag) sweep<T, D, R, RJ, true, UNIFORM, HOOK, EE, BINS>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count, bd);     \
-        else sweep<T, D, R, RJ, false, UNIFORM, HOOK, EE, BINS>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk.s_count, bd);         \
+        if (diag) sweep<T, D, R, RJ, true, UNIFORM, HOOK, EE, BINS>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk_s_count, bd);     \
+        else sweep<T, D, R, RJ, false, UNIFORM, HOOK, EE, BINS>(xi, gi, ai, xj, gj, aj, eps2, rot_addr, ga, wk_s_count, bd);         \
     } while (0)
                 if (HOOK == HOOK_GRID && degenerate) NB_SWEEP(GRID_DEGENERATE);
                 else if (HOOK == HOOK_GRID && fast && eps2 < (T)0.01) NB_SWEEP(GRID_FAST_CLAMP);
@@ -661,7 +673,7 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
         // column contributions of the super-row to these source slots of tile J: the diagonal sweep leaves aj
         // untouched (0), skipped waves hold 0; add the four waves in a fixed order and write ONE slab entry.
         // After s_count rotations lane l holds the accumulators of particle (l + s_begin + s_count).
-        const int home = (lane + wk.s_begin + wk.s_count) & 63;
+        const int home = (lane + wk_s_begin + wk_s_count) & 63;
 #pragma unroll
         for (int r = 0; r < RJ; ++r)
 #pragma unroll
@@ -691,6 +703,27 @@ force_sym_kernel(const T *__restrict__ packed, const SymWork *__restrict__ work,
             }
         atomicAdd(&bin_out[2 * (size_t)bin_n], (unsigned long long)bd.fast_pairs);
         atomicAdd(&bin_out[2 * (size_t)bin_n + 1], (unsigned long long)bd.exact_pairs);
+    }
+    if constexpr (RS_OK) {
+        if (rowsplit) {
+            // the four waves' sums of the one target tile, added in wave order (s_aj is free after the last barrier of
+            // the source loop and has exactly W x R x D x 64 elements of T = double)
+            static_assert(!RS_OK || sizeof(s_aj) == sizeof(double) * W * R * D * 64, "row-split reuses the column buffer");
+            double *s_rc = reinterpret_cast<double *>(&s_aj[0][0][0][0]);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int k = 0; k < D; ++k) s_rc[((wave * R + r) * D + k) * 64 + lane] = row_ref(r, k);
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < R * D * 64; idx += NB_BLOCK) {
+                const int l = idx & 63, rk = idx >> 6;         // rk = r * D + k
+                double v = s_rc[rk * 64 + l];
+#pragma unroll
+                for (int w = 1; w < W; ++w) v += s_rc[(w * R * D + rk) * 64 + l];
+                rowslab[((size_t)wk.slot * D + (rk % D)) * B + (rk / D) * 64 + l] = v;
+            }
+            return;
+        }
     }
     // row sums: one compact slot per (row, chunk)
     const int slot = wk.slot + wave * wk.slot_stride;
@@ -744,6 +777,20 @@ hipError_t launch_sym_u(const T *packed, const SymWork *work, int nwork, double 
     }
     return launch_sym_lpc<T, D, R, HOOK, NB_LUT_MIN, BINS>(packed, work, nwork, rowslab, colslab, np, uniform, eps2, tab,
                                                            gfac, st, ev, mass_value, bin_out, bin_n);
+}
+
+// row-split instantiations (fp64, D = 2, R = 4, no grid hook): see force_sym_kernel
+template <int HOOK>
+hipError_t launch_sym_rowsplit(const double *packed, const SymWork *work, int nwork, double *rowslab, double *colslab, int np,
+                               int uniform, double eps2, float gfac, hipStream_t st, NbKernelEvents ev)
+{
+    if (uniform)
+        hipExtLaunchKernelGGL((force_sym_kernel<double, 2, 4, true, HOOK, NB_LUT_MIN, false, true>), dim3(nwork), dim3(NB_BLOCK), 0, st,
+                              ev.start, ev.stop, 0, packed, work, rowslab, colslab, np, eps2, nullptr, gfac, 0.0f, nullptr, 0);
+    else
+        hipExtLaunchKernelGGL((force_sym_kernel<double, 2, 4, false, HOOK, NB_LUT_MIN, false, true>), dim3(nwork), dim3(NB_BLOCK), 0, st,
+                              ev.start, ev.stop, 0, packed, work, rowslab, colslab, np, eps2, nullptr, gfac, 0.0f, nullptr, 0);
+    return hipGetLastError();
 }
 
 }  // namespace

@@ -120,7 +120,7 @@ hipError_t nb_launch_pack(void *pos, void *vel, const void *acc, const void *mas
                           int spread_pad = 0 /* padding particles at distinct far positions (uniform-mass potential energy) */);
 hipError_t nb_launch_force_sym_f64(const double *packed, const SymWork *work, int nwork, double *rowslab,
                                    double *colslab, int np, int dim, int r, int uniform, int pa_f32, double eps2,
-                                   hipStream_t st, NbKernelEvents ev = {});
+                                   hipStream_t st, NbKernelEvents ev = {}, int rowsplit = 0 /* row-split work items (nb_plan.cpp) */);
 hipError_t nb_launch_force_sym_f32(const float *packed, const SymWork *work, int nwork, double *rowslab,
                                    float *colslab, int np, int dim, int r, int uniform, int hook, float eps2,
                                    const GridTables *tab, float G, float mass_value, int levels, hipStream_t st,

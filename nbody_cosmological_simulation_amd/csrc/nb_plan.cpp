@@ -21,6 +21,8 @@ NbKnobs nb_read_knobs()
     k.sym_cl = std::max(0, env_int("NB_SYM_CL", 0));
     k.sym_split = env_int("NB_SYM_SPLIT", 0);
     if (k.sym_split < 1 || k.sym_split > 16) k.sym_split = 0;
+    k.sym_rowsplit = env_int("NB_SYM_ROWSPLIT", -1);
+    if (k.sym_rowsplit > 8) k.sym_rowsplit = -1;
     k.tail_pieces = env_int("NB_SYM_TAIL", 0);
     if (k.tail_pieces != 2 && k.tail_pieces != 4 && k.tail_pieces != 8 && k.tail_pieces != 16) k.tail_pieces = 0;
     k.r_onesided = env_int("NB_R", 0);
@@ -136,6 +138,7 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
     // list runs dry.  The workgroup trace confirmed full residency until 1.05 of 1.15 ms instead of 0.75, and the launch
     // was no faster: fp64 N = 65 536 1203.7 -> 1204.9 us per step, 131 072 4817 -> 4771, FLOAT32 503.6 -> 509.0, INT8 785.1 ->
     // 782.3 (profiles/r03_guided_chunks_ab.txt).  One or two fp64 waves keep a SIMD's issue port nearly as busy as four.)
+    int rowsplit = 0;                     // > 0: row-split work items with this many step pieces per (row, source chunk)
     if (knobs.sym_split) {
         for (int S = 0; S < SR; ++S) split_of[S] = knobs.sym_split;
     } else if (sp.r == 4 && items < 1000) {
@@ -151,14 +154,32 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
         // of the sweep behind it (profiles/r03_mid_split_sweep.txt; fp64 us per step, pieces = 4 -> chosen: N = 5632
         // 28.0 -> 24.2, 6144 28.7 -> 25.0, 8192 39.3 -> 35.9, 10 240 50.6 -> 47.2, 14 336 79.5 -> 76.9).
         int pieces = 4;
-        if (items < 500) {
+        {
             const double t_step[4] = {0.70, 0.60, 0.62, 0.55};      // us per rotation step with 1 .. 4 resident waves per SIMD
             double best = 1e30;
             for (int nsp : {2, 3, 4, 5, 6, 8}) {
+                if (items >= 500 && nsp != 4) continue;             // (the sweep behind the model ends there: four pieces)
                 const long long wgs = items * nsp, rounds = (wgs + in.cus - 1) / in.cus;
                 const double cost = rounds * ((64 + nsp - 1) / nsp + 1) * t_step[std::min<long long>(rounds, 4) - 1] +
-                                    1.5 * (double)wgs / in.cus;
+                                    0.3 * 5.0 * (double)wgs / in.cus;          // 4 row slots + 1 slab entry per workgroup
                 if (cost < best) { best = cost; pieces = nsp; }
+            }
+            // ROW-SPLIT work items (fp64, 2-D): a workgroup = ONE target tile whose rotation steps its four waves share --
+            // the granularity of a quarter sweep of a super-row, but one row slot + one slab entry to reduce instead of
+            // four + one (the reduction is bound by exactly that traffic).  Same model: a wave runs 64 / (4 nsp) steps; a
+            // slab entry per tile instead of per super-row makes the reduction's items dearer (0.5 against 0.3 per unit).
+            // Measured fp64 us per step, classic -> chosen (profiles/r03_rowsplit_sweep.txt): N = 5120 20.4 -> 18.2, 7168
+            // 30.4 -> 26.9, 8192 35.9 -> 33.7, 12 288 62.0 -> 56.1, 16 384 96.6 -> 93.3.
+            if (is_f64 && dim == 2 && cl == 1 && knobs.sym_rowsplit != 0) {
+                long long rows_units = 0;
+                for (int S = 0; S < SR; ++S)
+                    if (ord[S] >= 0) for (int w = 0; w < 4; ++w) rows_units += std::max(0, T - (4 * S + w));
+                for (int nsp : {1, 2, 3, 4}) {
+                    const long long wgs = rows_units * nsp, rounds = (wgs + in.cus - 1) / in.cus;
+                    const double cost = rounds * ((64 + 4 * nsp - 1) / (4 * nsp) + 1) * t_step[std::min<long long>(rounds, 4) - 1] +
+                                        0.5 * 2.0 * (double)wgs / in.cus;
+                    if (cost < best) { best = cost; rowsplit = nsp; }
+                }
             }
         }
         for (int S = 0; S < SR; ++S) split_of[S] = pieces;
@@ -189,9 +210,34 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
         }
     }
 
+    if (knobs.sym_rowsplit > 0 && is_f64 && dim == 2 && sp.r == 4 && in.mode == NB_FLOAT64) rowsplit = knobs.sym_rowsplit;   // A/B knob
+    if (in.mode != NB_FLOAT64) rowsplit = 0;
+
     // ---- work items, slots, slab entries ---------------------------------------------------------------
     std::vector<SymWork> items_v;
     int slots = 0, ncol = 0;
+    if (rowsplit > 0) {
+        // one workgroup per (target tile I, source chunk, step piece q); slab entries per (I, q), numbered by ascending
+        // tile so that the entries tile J needs -- those of the owned tiles I < J -- form a prefix
+        const int nsp = rowsplit;
+        sp.col_upto.assign(sp.tiles, 0);
+        for (int I = 0; I < sp.tiles; ++I) {
+            sp.col_upto[I] = ncol;
+            sp.row_slot0[I] = slots;
+            sp.row_nslots[I] = 0;
+            if (I >= T || ord[I >> 2] < 0) continue;
+            const int nch = (T - I + cl - 1) / cl;
+            sp.row_nslots[I] = nch * nsp;
+            for (int ch = 0; ch < nch; ++ch)
+                for (int q = 0; q < nsp; ++q) {
+                    const int s0 = 64 * q / nsp, s1 = 64 * (q + 1) / nsp;
+                    items_v.push_back(SymWork{I, I + ch * cl, std::min(T, I + (ch + 1) * cl), slots + ch * nsp + q, -1,
+                                              ncol + q, s0, s1 - s0});
+                }
+            slots += nch * nsp;
+            ncol += nsp;
+        }
+    } else {
     for (int S = 0; S < SR; ++S) {
         if (ord[S] < 0) continue;
         const int j0 = 4 * S;
@@ -218,11 +264,13 @@ void nb_plan_sym(const PlanInput &in, const NbKnobs &knobs, SymPlanHost &sp)
         for (int S = 0; S < SR; ++S) first[S + 1] = first[S] + (ord[S] >= 0 ? split_of[S] : 0);
         for (int J = 0; J < sp.tiles; ++J) sp.col_upto[J] = first[(J >> 2) + ((J & 3) ? 1 : 0)];
     }
+    }
     // whole sweeps first, pieces last (longest processing time first)
     std::stable_sort(items_v.begin(), items_v.end(), [](const SymWork &a, const SymWork &b) {
         return (long long)(a.jt_end - a.jt_begin) * a.s_count > (long long)(b.jt_end - b.jt_begin) * b.s_count;
     });
     sp.work = std::move(items_v);
+    sp.rowsplit = rowsplit;
     sp.nslots = slots;
     sp.ncol = ncol;
     sp.col_bytes = (size_t)dim * sp.np * el * (size_t)std::max(ncol, 1);

@@ -16,6 +16,7 @@ struct NbKnobs {
     int sym_r = 0;         // NB_SYM_R: targets per lane (1, 2, 4); 0 = by size
     int sym_cl = 0;        // NB_SYM_CL: source tiles per work item; 0 = by work
     int sym_split = 0;     // NB_SYM_SPLIT: cut EVERY sweep into 1 ... 16 pieces; 0 = the plan's own choice
+    int sym_rowsplit = -1; // NB_SYM_ROWSPLIT: row-split work items (fp64, 2-D, R = 4): -1 = the plan's choice, 0 = never, n = always, n step pieces
     int tail_pieces = 0;   // NB_SYM_TAIL: pieces per sweep of the tail-smoothed super-rows (4 or 8); 0 = auto
     int r_onesided = 0;    // NB_R: targets per thread of the one-sided fp64 kernel
     bool no_prune = false;   // NB_NO_PRUNE: all-pairs max-r2 scan at any N
@@ -37,6 +38,7 @@ NbKnobs nb_read_knobs();
 struct SymPlanHost {
     bool enabled = false;
     int r = 2, tile_b = 128, tiles = 0, np = 0, nslots = 0, ncol = 0, cl = 1;
+    int rowsplit = 0;                                // > 0: row-split work items (slot_stride < 0) with this many step pieces
     std::vector<SymWork> work;                       // longest first
     std::vector<int> row_slot0, row_nslots, col_upto;   // per tile (see reduce_sym_kernel)
     size_t col_bytes = 0, row_bytes = 0, packed_bytes = 0;

@@ -132,6 +132,7 @@ struct nb_sim {
     // pair-symmetric path (nb_force_sym.hip): device mirror of the host plan (nb_plan.h)
     struct SymPlan {
         bool enabled = false;
+        bool rowsplit = false;            // row-split work items: force_sym_kernel's RSPLIT instantiations
         int r = 2, tile_b = 128, tiles = 0, np = 0, nwork = 0, nslots = 0;
         SymWork *work = nullptr;
         int *row_slot0 = nullptr, *row_nslots = nullptr, *col_upto = nullptr;

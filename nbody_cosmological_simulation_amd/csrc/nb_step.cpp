@@ -206,7 +206,7 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready, bool *defer_kick, boo
             if (int rc = prof_begin(s, &slot, false)) return rc;
             HIPCHK(nb_launch_force_sym_f64((const double *)sp.packed, sp.work, sp.nwork, sp.rowslab,
                                            (double *)sp.colslab, sp.np, c.dim, sp.r, s->mass_uniform, pa_f32,
-                                           c.softening_sq, s->stream, prof_events(s, slot)));
+                                           c.softening_sq, s->stream, prof_events(s, slot), sp.rowsplit ? 1 : 0));
             s->last_kernel = "force_sym_kernel<double";
         } else {
             if (int rc = prof_begin(s, &slot)) return rc;

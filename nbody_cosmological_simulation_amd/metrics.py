@@ -120,9 +120,10 @@ def collect_metrics(simulation, tick: int, metrics: SimulationMetrics):
     """Append every diagnostic for the current state (reference metrics.py:159-179): energies and all four
     diagnostics from the engine's device-resident state, one native evaluation, no state download."""
     metrics.ticks.append(tick)
+    total = simulation.get_total_energy()          # both parts from one native evaluation; the getters below hit its memo
     metrics.kinetic_energy.append(simulation.get_kinetic_energy())
     metrics.potential_energy.append(simulation.get_potential_energy())
-    metrics.total_energy.append(simulation.get_total_energy())
+    metrics.total_energy.append(total)
     if hasattr(simulation, "_native_metrics_ready") and simulation._native_metrics_ready():
         m = native_metrics(None, None, None, simulation=simulation)
     else:                       # another object with the same attributes (or an empty galaxy): through the tensors

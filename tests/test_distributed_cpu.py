@@ -141,11 +141,12 @@ def test_symmetric_plans_cover_every_tile_pair_once(monkeypatch, n, is_f64, worl
         npairs = 0
         col_of_row = {}
         for idx, (ti, jb, je, slot, stride, col, sb, sc) in enumerate(w):
-            assert ti % 4 == 0 and ti <= jb < je <= T and 0 <= sb and sc > 0 and sb + sc <= 64
+            rowsplit = stride < 0        # one target tile per workgroup, its four waves share the steps [sb, sb + sc)
+            assert (rowsplit or ti % 4 == 0) and ti <= jb < je <= T and 0 <= sb and sc > 0 and sb + sc <= 64
             mask = np.uint64(((1 << int(sc)) - 1) << int(sb))
-            for wv in range(4):
+            for wv in range(1 if rowsplit else 4):
                 I = ti + wv
-                sl = slot + wv * stride
+                sl = slot if rowsplit else slot + wv * stride
                 assert 0 <= sl < p["nslots"]
                 used_slots[sl] += 1
                 assert p["row_slot0"][I] <= sl < p["row_slot0"][I] + p["row_nslots"][I]
@@ -156,6 +157,7 @@ def test_symmetric_plans_cover_every_tile_pair_once(monkeypatch, n, is_f64, worl
                     steps[I, J] |= mask
                     npairs += int(sc)
             col_of_row.setdefault(int(ti), set()).add(int(col))
+            rowsplit_plan = bool(rowsplit)
         assert np.all(used_slots == 1), "row slots must be written exactly once"
         assert int(p["row_nslots"].sum()) == p["nslots"]
         # column-slab prefix of tile J = entries of the owned super-rows that start above J
@@ -193,15 +195,28 @@ def test_sweep_pieces_need_not_divide_64(monkeypatch, split):
 
 
 def test_mid_size_pieces_follow_the_cost_model():
-    """fp64 mid sizes: pieces per sweep from the measured cost model of nb_plan.cpp (profiles/r03_mid_split_sweep.txt):
-    N = 5120 (60 items) 4, 6144 (84) 3 or 6, 8192 (144) 3, 10 240 (220) 2; 500 items and more keep 4."""
-    def pieces(n):
-        p = _plan(n, 2, 0, 1, is_f64=True)
-        items = {(int(w[0]), int(w[1])) for w in p["work"]}
-        return p["nwork"] // len(items)
-    assert pieces(5120) == 4 and pieces(8192) == 3 and pieces(10240) == 2
-    assert pieces(6144) in (3, 6)
-    assert pieces(16384) == 4
+    """fp64 mid sizes: classic pieces per sweep or row-split work items, chosen by the measured cost model of nb_plan.cpp
+    (profiles/r03_mid_split_sweep.txt, profiles/r03_rowsplit_sweep.txt).  Row-split (one target tile per workgroup, its
+    four waves share the steps, slot_stride < 0) only for FLOAT64 plans in 2-D; large systems keep whole sweeps."""
+    def shape(n, **kw):
+        p = _plan(n, kw.pop("dim", 2), 0, 1, is_f64=kw.pop("is_f64", True))
+        w = p["work"]
+        items = {(int(x[0]), int(x[1])) for x in w}
+        return ("rowsplit" if int(w[0][4]) < 0 else "classic", p["nwork"] // len(items))
+    assert shape(5120) == ("rowsplit", 2) and shape(8192) == ("rowsplit", 2)
+    assert shape(9216) == ("rowsplit", 1) and shape(12288) == ("rowsplit", 1) and shape(16384) == ("rowsplit", 1)
+    assert shape(14336) == ("classic", 3)
+    assert shape(65536)[0] == "classic" and shape(24576)[0] == "classic"
+    assert shape(8192, dim=3)[0] == "classic" and shape(8192, is_f64=False)[0] == "classic"
+
+
+def test_rowsplit_knob(monkeypatch):
+    """NB_SYM_ROWSPLIT=0 keeps the classic work items, n > 0 forces row-split items with n step pieces."""
+    monkeypatch.setenv("NB_SYM_ROWSPLIT", "0")
+    assert int(_plan(8192, 2, 0, 1, is_f64=True)["work"][0][4]) > 0
+    monkeypatch.setenv("NB_SYM_ROWSPLIT", "3")
+    p = _plan(8192, 2, 0, 1, is_f64=True)
+    assert all(int(w[4]) < 0 for w in p["work"]) and p["nwork"] == 3 * (32 * 33 // 2)
 
 
 def _p2p_vote_worker(rank, world, port, out):

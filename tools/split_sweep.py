@@ -9,8 +9,12 @@ for n in ns:
     row = []
     for sp in splits:
         env = dict(os.environ, MODE=mode)
-        if sp != "0": env["NB_SYM_SPLIT"] = sp
-        else: env.pop("NB_SYM_SPLIT", None)
+        knob = os.environ.get("KNOB", "NB_SYM_SPLIT")        # KNOB=NB_SYM_ROWSPLIT SPLITS="d 0 1 2": "d" = knob unset
+        if knob == "NB_SYM_SPLIT":
+            if sp != "0": env[knob] = sp
+            else: env.pop(knob, None)
+        elif sp == "d": env.pop(knob, None)
+        else: env[knob] = sp
         out = subprocess.run([sys.executable, tool, n], env=env, capture_output=True, text=True).stdout
         row.append(out.split(":")[1].split("us")[0].strip() if "us/step" in out else "fail")
     print(f"{n:<7}" + "".join(f"{r:>10}" for r in row), flush=True)
