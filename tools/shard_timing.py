@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--mode", default="float64")
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--ranks", default="1,2,4,8")
-    ap.add_argument("--chunks", default="1,2")
+    ap.add_argument("--chunks", default="1", help="(ignored: the round-2 chunk pipeline was removed; kept so old command lines still parse)")
     ap.add_argument("--tail", default="4,8")
     ap.add_argument("--which", default="0", help="rank(s) whose share is timed: '0' or 'all'")
     args = ap.parse_args()
@@ -46,7 +46,6 @@ def main():
             worst = 0.0
             for r in ranks:
                 os.environ["NBODY_SHARD_TIMING"] = f"{r}/{P}"
-                os.environ["NB_CHUNKS"] = chunks
                 os.environ["NB_SYM_TAIL"] = tail
                 sim = nb.GalaxySimulation(pos.to(dev), vel.to(dev), mass.to(dev), precision_mode=mode, device=dev)
                 sim.run(60)
