@@ -394,6 +394,7 @@ int nb_cache_trim(int64_t *released_bytes)
 int nb_set_params(nb_sim *s, double G, double softening_sq, double dt)
 {
     if (!s) return fail(NB_ERR_INVALID, "null handle");
+    s->spec_open = false;          // state / parameters change: the speculative next positions are void
     s->cfg.G = G;
     s->cfg.softening_sq = softening_sq;
     s->cfg.dt = dt;
@@ -403,6 +404,7 @@ int nb_set_params(nb_sim *s, double G, double softening_sq, double dt)
 int nb_set_state(nb_sim *s, const void *pos, const void *vel, const void *mass, int dtype, int on_device)
 {
     if (!s) return fail(NB_ERR_INVALID, "null handle");
+    s->spec_open = false;          // state / parameters change: the speculative next positions are void
     if (dtype < NB_F16 || dtype > NB_F64) return fail(NB_ERR_INVALID, "bad dtype %d", dtype);
     DeviceGuard guard(s->cfg.device);
     const int mode = s->cfg.mode;
@@ -438,6 +440,7 @@ int nb_set_state(nb_sim *s, const void *pos, const void *vel, const void *mass, 
 int nb_set_accelerations(nb_sim *s, const void *acc, int dtype, int on_device)
 {
     if (!s || !acc) return fail(NB_ERR_INVALID, "null argument");
+    s->spec_open = false;
     if (!s->have_storage) return fail(NB_ERR_INVALID, "set the state first");
     if (dtype != NB_F32 && dtype != NB_F64) return fail(NB_ERR_UNSUPPORTED, "acceleration dtype %d", dtype);
     if (dtype == NB_F64 && !s->is_f64) return fail(NB_ERR_UNSUPPORTED, "fp64 accelerations on fp32 state");
@@ -472,6 +475,7 @@ int nb_get_state(nb_sim *s, void *pos, void *vel, void *acc, void *mass, int on_
 int nb_compute_accelerations(nb_sim *s)
 {
     if (!s) return fail(NB_ERR_INVALID, "null handle");
+    s->spec_open = false;          // state / parameters change: the speculative next positions are void
     DeviceGuard guard(s->cfg.device);
     return force_eval(s, false);
 }
@@ -479,6 +483,7 @@ int nb_compute_accelerations(nb_sim *s)
 int nb_kick_drift(nb_sim *s)
 {
     if (!s) return fail(NB_ERR_INVALID, "null handle");
+    s->spec_open = false;          // state / parameters change: the speculative next positions are void
     if (!s->have_vel || !s->have_pos || !s->have_acc) return fail(NB_ERR_INVALID, "state incomplete");
     DeviceGuard guard(s->cfg.device);
     HIPCHK(nb_launch_kick_drift(s->pos, s->vel, s->acc, s->cfg.dt / 2, s->cfg.dt, nd(s), s->is_f64, s->stream));
@@ -490,6 +495,7 @@ int nb_kick_drift(nb_sim *s)
 int nb_kick(nb_sim *s)
 {
     if (!s) return fail(NB_ERR_INVALID, "null handle");
+    s->spec_open = false;          // state / parameters change: the speculative next positions are void
     if (!s->have_vel || !s->have_acc) return fail(NB_ERR_INVALID, "state incomplete");
     DeviceGuard guard(s->cfg.device);
     HIPCHK(nb_launch_axpy(s->vel, s->acc, s->cfg.dt / 2, nd(s), s->is_f64, s->stream));

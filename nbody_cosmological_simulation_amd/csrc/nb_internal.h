@@ -285,7 +285,7 @@ int nb_small_lanes(int n);
 int nb_small_block(int n);          // threads per workgroup of the one-launch step at this size (256 or 512)
 hipError_t nb_launch_small_step(const void *pos_in, void *pos_out, void *vel, void *acc, const void *mass, int n, int dim,
                                 int is_f64, int hook, double G, double eps2, double half_dt, double dt,
-                                int do_kick /* 0 force only, 1 + closing kick, 2 + next opening kick + drift into pos_out */,
+                                int do_kick /* 0 force only, 1 + closing kick, 2 + next opening kick + drift into pos_out, 3 closing kick + speculative next positions into pos_out; | 4 opening kick on read */,
                                 int lanes /* 16 / 32 / 64 lanes per target */, hipStream_t st,
                                 const GridTables *tab = nullptr /* HOOK_GRID: this evaluation's tables */,
                                 double *part = nullptr /* INT8 / INT4: 2 n doubles, per-target min / max of the forces */,

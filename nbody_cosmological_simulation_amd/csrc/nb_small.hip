@@ -49,7 +49,9 @@ template <typename T> __device__ __forceinline__ T axpy_sep(T a, T b, T s);     
 template <> __device__ __forceinline__ double axpy_sep<double>(double a, double b, double s) { return __dadd_rn(a, __dmul_rn(b, s)); }
 template <> __device__ __forceinline__ float axpy_sep<float>(float a, float b, float s) { return __fadd_rn(a, __fmul_rn(b, s)); }
 
-// do_kick: 0 force only; 1 + closing half kick; 2 + next step's opening kick + drift (positions -> pos_out)
+// do_kick: 0 force only; 1 + closing half kick; 2 + next step's opening kick + drift (positions -> pos_out); 3 closing
+// kick + the next step's drifted positions speculatively into pos_out; | 4: vel holds the previous step's closing state,
+// this step's opening kick is applied on read with the previous accelerations
 // BINS (grid hook only): the same body with the quant-bin read-out -- per-target integer checksums s1 = sum_j k,
 // s2 = sum_j k ((j mod 65521) + 1) of the bin every pair was given, by whichever route the production code took
 // (table-free estimate / wave ballot / threshold fallback); bin_out = {s1[n], s2[n], {table-free pairs, table pairs}}.
@@ -248,15 +250,26 @@ small_step_kernel(const T *__restrict__ pos_in, T *__restrict__ pos_out, T *__re
         for (int k = 0; k < D; ++k) {
             const size_t idx = (size_t)i * D + k;
             const T ak = (T)a[k];
+            const T a_prev = (do_kick & 4) ? acc[idx] : (T)0;     // (read before this evaluation's force replaces it)
             acc[idx] = ak;
             const double av = (double)ak;              // NaN-propagating like torch's min() / max()
             lo = (av != av || lo != lo) ? __builtin_nan("") : (av < lo ? av : lo);
             hi = (av != av || hi != hi) ? __builtin_nan("") : (av > hi ? av : hi);
-            if (do_kick >= 1) {
-                T v = axpy_sep<T>(vel[idx], ak, half_dt);                 // closing kick (simulation.py:141)
-                if (do_kick == 2) {
+            const int kmode = do_kick & 3;
+            if (kmode >= 1) {
+                T v = vel[idx];
+                if (do_kick & 4) v = axpy_sep<T>(v, a_prev, half_dt);     // this step's opening kick, deferred (see below)
+                v = axpy_sep<T>(v, ak, half_dt);                          // closing kick (simulation.py:141)
+                if (kmode == 2) {
                     v = axpy_sep<T>(v, ak, half_dt);                      // next step's opening kick (:132)
                     pos_out[idx] = axpy_sep<T>(xi[k], v, dt);             // ... and drift (:135)
+                } else if (kmode == 3) {
+                    // last step of a native call: velocities stay at the closing kick (what a reader must see), but the
+                    // positions the NEXT step would drift to go to pos_out -- if the next nb_step finds the state
+                    // untouched it takes them and applies its opening kick here on read (flag 4): a Python loop of
+                    // step() costs one launch per step instead of two
+                    const T vo = axpy_sep<T>(v, ak, half_dt);
+                    pos_out[idx] = axpy_sep<T>(xi[k], vo, dt);
                 }
                 vel[idx] = v;
             }

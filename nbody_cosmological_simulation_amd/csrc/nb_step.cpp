@@ -458,14 +458,27 @@ int step_small(nb_sim *s, int nsteps, bool opened)
     if (fq && !s->small_part) HIPCHK(hipMalloc((void **)&s->small_part, 2 * (size_t)c.n * sizeof(double)));
     const int hook = grid ? HOOK_GRID : (c.mode == NB_BFLOAT16 ? HOOK_BF16 : (c.mode == NB_FLOAT16 ? HOOK_F16 : HOOK_NONE));
     const int lanes = s->knobs.small_lanes ? s->knobs.small_lanes : nb_small_lanes(c.n);
-    if (!opened)
-        HIPCHK(nb_launch_kick_drift(s->pos, s->vel, s->acc, c.dt / 2, c.dt, nd(s), s->is_f64, s->stream));
+    // A step() loop driven from Python is one nb_step(1) per tick: the last step of a call leaves the next step's
+    // drifted positions in pos_alt (kick mode 3); if nothing wrote state or dt since, this call takes them and applies
+    // its opening kick on read -- one launch per tick instead of two (FLOAT32 us per step() call: N = 1024 9.9 -> 5.6, N = 3000 12.6 -> 10.8;
+    // profiles/r03_python_step_overhead.txt)
+    const bool speculate = !grid && !fq;
+    bool open_on_read = false;
+    if (!opened) {
+        if (speculate && s->spec_open && s->spec_dt == c.dt) {
+            std::swap(s->pos, s->pos_alt);
+            open_on_read = true;
+        } else {
+            HIPCHK(nb_launch_kick_drift(s->pos, s->vel, s->acc, c.dt / 2, c.dt, nd(s), s->is_f64, s->stream));
+        }
+    }
+    s->spec_open = false;
     for (int t = 0; t < nsteps; ++t) {
         const bool last = (t + 1 == nsteps);
         if (grid)
             if (int rc = small_grid_tables(s)) return rc;
         // INT8 / INT4: the forces are snapped to their grid (and the kicks applied) by the finish launch
-        const int kick = fq ? 0 : (last ? 1 : 2);
+        const int kick = fq ? 0 : ((last ? (speculate ? 3 : 1) : 2) | ((t == 0 && open_on_read) ? 4 : 0));
         int slot;
         if (int rc = prof_begin(s, &slot)) return rc;
         HIPCHK(nb_launch_small_step(s->pos, s->pos_alt, s->vel, s->acc, s->mass, c.n, c.dim, s->is_f64, hook, c.G,
@@ -479,6 +492,7 @@ int step_small(nb_sim *s, int nsteps, bool opened)
         else if (!last)
             std::swap(s->pos, s->pos_alt);
     }
+    if (speculate) { s->spec_open = true; s->spec_dt = c.dt; }
     s->last_kernel = "small_step_kernel";
     s->last_generic = false;
     return NB_OK;
@@ -495,6 +509,7 @@ int step_run(nb_sim *s, int nsteps)
     for (int t = 0; t < nsteps; ++t) {
         // small systems with settled dtypes: one launch per step
         if (!pending_close && small_ok(s)) return step_small(s, nsteps - t, opened);
+        s->spec_open = false;
         // opening kick + drift; on the pair-symmetric path the repack rides in the same launch
         const int sdt = s->is_f64 ? NB_F64 : NB_F32;
         const bool fuse_pack = s->sym.enabled && s->logical[0] == sdt && s->logical[1] == sdt &&
