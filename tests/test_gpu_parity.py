@@ -2327,3 +2327,58 @@ def test_handle_cache_reuse_is_invisible(nb):
         x1, v1, e1 = run(m)
         assert torch.equal(x0, x1) and torch.equal(v0, v1) and e0 == e1, m
     assert runtime.trim_cache() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["float64", "float32"])
+def test_step_loop_speculation_is_dropped_by_every_write(nb, monkeypatch, mode):
+    """A Python loop of step() on a small system takes the next step's drifted positions from the previous call
+    (nb_step.cpp: step_small).  Every write in between -- dt, G, softening, positions, velocities, masses,
+    accelerations, an explicit force evaluation -- must void them: the same sequence on the tiled kernels (no
+    speculation there) agrees to rounding, and a step() loop equals one run() call bit for bit."""
+    from nbody_cosmological_simulation_amd import galaxy
+    pos, vel, mass = galaxy.create_disk_galaxy(700, seed=11, device="cpu")
+    pm = nb.PrecisionMode(mode)
+
+    def script(sim):
+        out = []
+        sim.step(); sim.step()
+        sim.dt = 0.02
+        sim.step(); out.append(sim.positions.clone())
+        sim.G = 0.002
+        sim.step()
+        sim.velocities = sim.velocities * 0.5          # rebinding: uploaded before the next step
+        sim.step(); out.append(sim.velocities.clone())
+        sim.positions[:10] += 0.25                       # in-place edit of the downloaded tensor
+        sim.step()
+        sim.softening_sq = 0.02
+        sim.masses = sim.masses * 2.0
+        sim.step(); out.append(sim.positions.clone())
+        sim.accelerations = sim._compute_accelerations()
+        sim.step(); sim.step()
+        sim.dt = 0.01
+        sim.run(3)
+        sim.step()
+        out += [sim.positions.clone(), sim.velocities.clone()]
+        return out
+
+    a = script(nb.GalaxySimulation(pos, vel, mass, precision_mode=pm))
+    monkeypatch.setenv("NB_NO_SMALLN", "1")
+    tiled = nb.GalaxySimulation(pos, vel, mass, precision_mode=pm)
+    monkeypatch.delenv("NB_NO_SMALLN")
+    b = script(tiled)
+    assert tiled.force_kernel_name() != "small_step_kernel"
+    tol = 1e-11 if mode == "float64" else 2e-5
+    for x, y in zip(a, b):
+        assert relerr(x.numpy(), y.numpy()) < tol
+    # step() loop == run(): bit for bit, including across reads of the state
+    s1 = nb.GalaxySimulation(pos, vel, mass, precision_mode=pm)
+    s2 = nb.GalaxySimulation(pos, vel, mass, precision_mode=pm)
+    for k in range(7):
+        s1.step()
+        if k == 3:
+            _ = s1.get_total_energy(), s1.positions
+    s2.run(7)
+    assert s1.force_kernel_name() == "small_step_kernel"
+    assert torch.equal(s1.positions, s2.positions) and torch.equal(s1.velocities, s2.velocities)
+    assert torch.equal(s1.accelerations, s2.accelerations)
