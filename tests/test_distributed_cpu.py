@@ -157,7 +157,6 @@ def test_symmetric_plans_cover_every_tile_pair_once(monkeypatch, n, is_f64, worl
                     steps[I, J] |= mask
                     npairs += int(sc)
             col_of_row.setdefault(int(ti), set()).add(int(col))
-            rowsplit_plan = bool(rowsplit)
         assert np.all(used_slots == 1), "row slots must be written exactly once"
         assert int(p["row_nslots"].sum()) == p["nslots"]
         # column-slab prefix of tile J = entries of the owned super-rows that start above J
