@@ -84,7 +84,8 @@ struct HandleCache {
     size_t total = 0, entries = 0;
     bool off = getenv("NB_NO_CACHE") != nullptr;
 };
-HandleCache g_cache;
+// never destroyed: handles may still be closed (Python finalisers) while the process runs its static destructors
+HandleCache &g_cache = *new HandleCache;
 
 int device_cus(int device)
 {
