@@ -85,7 +85,7 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
                   const int *__restrict__ col_upto, int tile_b, int n, int np,
                   double scale, T *__restrict__ acc, T *__restrict__ vel, T half_dt, int do_kick,
                   T *__restrict__ pos, T *__restrict__ packed, T dt, int blk0, double *__restrict__ sums64,
-                  double *__restrict__ mm_part)
+                  double *__restrict__ mm_part, T *__restrict__ pos_next)
 {
     __shared__ double s_part[NB_RED_WAVES][D][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -129,23 +129,40 @@ reduce_sym_kernel(const double *__restrict__ rowslab, const T *__restrict__ cols
                 continue;
             }
             const T a = (T)(t * scale);            // scale = mass factor of the uniform kernel, else 1
+            // do_kick bit 2: the velocities hold the previous step's CLOSING state and the positions were taken from its
+            // speculative drift -- this step's opening kick is applied here, with the accelerations being replaced
+            const T a_prev = (do_kick & 4) ? acc[idx] : (T)0;
             acc[idx] = a;
             if (mm_part) {
                 const double ad = (double)a;
                 mm_lo = (ad != ad || mm_lo != mm_lo) ? __builtin_nan("") : (ad < mm_lo ? ad : mm_lo);
                 mm_hi = (ad != ad || mm_hi != mm_hi) ? __builtin_nan("") : (ad > mm_hi ? ad : mm_hi);
             }
-            if (do_kick == 1) {
-                vel[idx] = axpy_rn<T>(vel[idx], a, half_dt);
-            } else if (do_kick == 2) {
-                // closing kick, then the next step's opening kick + drift and its repack (what pack_kernel<KICK=1>
-                // would do in a launch of its own; mass factors and padding in `packed` do not change)
-                T v = axpy_rn<T>(vel[idx], a, half_dt);
-                v = axpy_rn<T>(v, a, half_dt);
-                const T x = axpy_rn<T>(pos[idx], v, dt);
-                vel[idx] = v;
-                pos[idx] = x;
-                packed[(size_t)k * np + p] = x;
+            const int kmode = do_kick & 3;
+            if (kmode != 0) {
+                T v = vel[idx];
+                if (do_kick & 4) v = axpy_rn<T>(v, a_prev, half_dt);
+                v = axpy_rn<T>(v, a, half_dt);                                   // closing kick
+                if (kmode == 1) {
+                    vel[idx] = v;
+                } else if (kmode == 2) {
+                    // ... then the next step's opening kick + drift and its repack (what pack_kernel<KICK=1>
+                    // would do in a launch of its own; mass factors and padding in `packed` do not change)
+                    v = axpy_rn<T>(v, a, half_dt);
+                    const T x = axpy_rn<T>(pos[idx], v, dt);
+                    vel[idx] = v;
+                    pos[idx] = x;
+                    packed[(size_t)k * np + p] = x;
+                } else {
+                    // last step of a native call: the state stays at the closing kick (what a reader must see); the
+                    // positions the NEXT step drifts to go to pos_next and, packed, to the force kernel's input.  The next
+                    // nb_step takes them if nothing wrote state, dt or `packed` in between (nb_step.cpp: step_run)
+                    vel[idx] = v;
+                    const T vo = axpy_rn<T>(v, a, half_dt);
+                    const T x = axpy_rn<T>(pos[idx], vo, dt);
+                    pos_next[idx] = x;
+                    packed[(size_t)k * np + p] = x;
+                }
             }
         }
     }
@@ -476,8 +493,9 @@ hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, cons
                                 const int *row_nslots, const int *col_upto, int tile_b, int n,
                                 int np, int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
                                 int do_kick, void *pos, void *packed, double dt, hipStream_t st, int p_begin, int p_end,
-                                double *sums64, double *mm_part)
+                                double *sums64, double *mm_part, void *pos_next)
 {
+    if ((do_kick & 3) == 3 && !pos_next) return hipErrorInvalidValue;
     if (p_end < 0 || p_end > n) p_end = n;
     if (p_end <= p_begin) return hipSuccess;
     const int blk0 = p_begin / 64;                  // chunk boundaries are tile boundaries (multiples of 64)
@@ -485,7 +503,7 @@ hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, cons
 #define NB_RED(TT, DD) \
     hipLaunchKernelGGL((reduce_sym_kernel<TT, DD>), dim3(grid), dim3(64 * NB_RED_WAVES), 0, st, rowslab, (const TT *)colslab, \
                        row_slot0, row_nslots, col_upto, tile_b, n, np, scale, (TT *)acc, (TT *)vel, (TT)half_dt, do_kick, \
-                       (TT *)pos, (TT *)packed, (TT)dt, blk0, sums64, mm_part)
+                       (TT *)pos, (TT *)packed, (TT)dt, blk0, sums64, mm_part, (TT *)pos_next)
     if (dim != 2 && dim != 3) return hipErrorInvalidValue;
     if (is_f64) { if (dim == 2) NB_RED(double, 2); else NB_RED(double, 3); }
     else        { if (dim == 2) NB_RED(float, 2); else NB_RED(float, 3); }

@@ -132,11 +132,12 @@ hipError_t nb_launch_final_sum(const double *part, int count, double *out, hipSt
 hipError_t nb_launch_reduce_sym(const double *rowslab, const void *colslab, const int *row_slot0,
                                 const int *row_nslots, const int *col_upto, int tile_b, int n,
                                 int np, int dim, int is_f64, double scale, void *acc, void *vel, double half_dt,
-                                int do_kick /* 1: closing kick, 2: + next opening kick + drift + repack */,
+                                int do_kick /* 1: closing kick, 2: + next opening kick + drift + repack, 3: closing kick + the next step's positions speculatively into pos_next / packed; | 4: this step's opening kick on read */,
                                 void *pos, void *packed, double dt, hipStream_t st,
                                 int p_begin = 0, int p_end = -1 /* particles [p_begin, p_end); -1 = n */,
                                 double *sums64 = nullptr /* instead of acc / kicks: the unscaled, unrounded fp64 sums */,
-                                double *mm_part = nullptr /* per-workgroup {min, max} of the forces written (whole-range launches) */);
+                                double *mm_part = nullptr /* per-workgroup {min, max} of the forces written (whole-range launches) */,
+                                void *pos_next = nullptr /* do_kick mode 3 */);
 // fp32 state, multi-GPU: acc = (float)(sums64 * scale) after the ranks' fp64 sums were added, + the kicks of mode
 // (0 none, 1 closing, 2 closing + next opening + drift + repack) -- the tail of reduce_sym_kernel, after the exchange
 hipError_t nb_launch_finish_sums64(const double *sums64, double scale, float *acc, float *vel, float *pos, float *packed,

@@ -35,6 +35,7 @@ NbKnobs nb_read_knobs()
     k.no_p2p = getenv("NB_NO_P2P") != nullptr;
     k.no_p2p_kick = getenv("NB_P2P_NO_KICK") != nullptr;
     k.no_small_fuse = getenv("NB_NO_SMALL_FUSE") != nullptr;
+    k.no_spec = getenv("NB_NO_SPEC") != nullptr;
     k.no_x64 = getenv("NB_NO_X64") != nullptr;
     k.no_red_mm = getenv("NB_NO_RED_MM") != nullptr;
     k.small_max = std::max(0, env_int("NB_SMALL_MAX", 0));

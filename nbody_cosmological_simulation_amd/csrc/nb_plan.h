@@ -32,6 +32,7 @@ struct NbKnobs {
     bool no_x64 = false;         // NB_NO_X64: multi-GPU fp32 modes exchange fp32 partial forces (not the fp64 sums)
     bool no_small_fuse = false;  // NB_NO_SMALL_FUSE: small grid steps launch max-r2 and tables separately (A/B)
     bool no_p2p_kick = false;    // NB_P2P_NO_KICK: the direct all-reduce does not fuse the kicks / drift / repack (A/B)
+    bool no_spec = false;        // NB_NO_SPEC: the last step of a native call does not leave the next step's positions (A/B, tests)
 };
 NbKnobs nb_read_knobs();
 

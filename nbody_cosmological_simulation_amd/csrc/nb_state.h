@@ -142,6 +142,9 @@ struct nb_sim {
     void *pos_alt = nullptr;             // small-N single-launch step: positions ping-pong between pos and pos_alt
     bool spec_open = false;              // ... pos_alt holds the positions the NEXT step drifts to (computed with spec_dt by
     double spec_dt = 0.0;                //     the last step of the previous nb_step); dropped by every entry that writes state
+    int spec_kind = 0;                   //     1: left by the small-system kernel, 2: by reduce_sym_kernel (sym.packed holds them too)
+    bool req_spec_next = false;          // step_run -> force_eval: last step of a call, leave the next step's positions
+    bool req_open_on_read = false;       // step_run -> force_eval: this step started from speculative positions
     double *small_part = nullptr;        // ... INT8 / INT4: per-target min / max of the forces (2 n doubles)
     void *gen_scalars = nullptr;         // generic (dtype-faithful) path: device scalars of one evaluation
     bool last_generic = false;           // the last force evaluation ran on the generic path (no threshold tables)

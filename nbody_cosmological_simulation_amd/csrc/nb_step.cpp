@@ -182,7 +182,10 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready, bool *defer_kick, boo
     if (multi)
         if (int rc = comm_check(s)) return rc;
     if (no_comm && c.nranks > 1 && do_kick) return fail(NB_ERR_INVALID, "NB_FLAG_NO_COMM handles cannot step");
-    if (use_generic(s)) return force_eval_generic(s, do_kick, defer_kick, open_next);
+    if (use_generic(s)) {
+        if (s->req_open_on_read) return fail(NB_ERR_INVALID, "internal: speculative positions on the generic path");
+        return force_eval_generic(s, do_kick, defer_kick, open_next);
+    }
     s->last_generic = false;
     int slot;
     bool used_sym = false, sym_uniform = false;
@@ -335,13 +338,28 @@ int force_eval(nb_sim *s, bool do_kick, bool packed_ready, bool *defer_kick, boo
         if (sym_uniform) scale = s->is_f64 ? c.G * s->mass_value : (double)((float)c.G * (float)s->mass_value);
         // inside nb_step the reduction also opens the next step and repacks its positions
         const bool open = fuse_kick && want_open;
+        int kmode = open ? 2 : (fuse_kick ? 1 : 0);
+        // the last step of a native call leaves the NEXT step's drifted positions in pos_alt and `packed` (mode 3); a
+        // call that starts from them applies its opening kick on read (bit 2) -- a Python loop of step() then costs
+        // force + reduction per tick, no pack launch (see step_run)
+        const bool spec = fuse_kick && !open && s->req_spec_next && !grid_mode(c.mode);
+        if (spec) {
+            if (!s->pos_alt) HIPCHK(hipMalloc(&s->pos_alt, (size_t)cnt * (s->is_f64 ? 8 : 4)));
+            kmode = 3;
+        }
+        if (s->req_open_on_read) {
+            if (!fuse_kick) return fail(NB_ERR_INVALID, "internal: a step started from speculative positions cannot fuse its kicks");
+            kmode |= 4;
+        }
         HIPCHK(nb_launch_reduce_sym(sp.rowslab, sp.colslab, sp.row_slot0, sp.row_nslots, sp.col_upto,
                                     sp.tile_b, c.n, sp.np, c.dim, s->is_f64, scale, red_out, s->vel, half_dt,
-                                    open ? 2 : (fuse_kick ? 1 : 0), s->pos, sp.packed, c.dt, s->stream, 0, -1, sums64,
-                                    red_mm ? s->scalars + 8 : nullptr));
+                                    kmode, s->pos, sp.packed, c.dt, s->stream, 0, -1, sums64,
+                                    red_mm ? s->scalars + 8 : nullptr, s->pos_alt));
+        if (spec) { s->spec_open = true; s->spec_kind = 2; s->spec_dt = c.dt; }
         x64_scale = scale;
         opened = open;
     } else {
+        if (s->req_open_on_read) return fail(NB_ERR_INVALID, "internal: speculative positions on the one-sided path");
         // one-sided path inside nb_step: the reduction can also open the next step (one launch fewer per step,
         // which is what small systems are bound by)
         const bool open = fuse_kick && want_open;
@@ -462,10 +480,10 @@ int step_small(nb_sim *s, int nsteps, bool opened)
     // drifted positions in pos_alt (kick mode 3); if nothing wrote state or dt since, this call takes them and applies
     // its opening kick on read -- one launch per tick instead of two (FLOAT32 us per step() call: N = 1024 9.9 -> 5.6, N = 3000 12.6 -> 10.8;
     // profiles/r03_python_step_overhead.txt)
-    const bool speculate = !grid && !fq;
+    const bool speculate = !grid && !fq && !s->knobs.no_spec;
     bool open_on_read = false;
     if (!opened) {
-        if (speculate && s->spec_open && s->spec_dt == c.dt) {
+        if (speculate && s->spec_open && s->spec_kind == 1 && s->spec_dt == c.dt) {
             std::swap(s->pos, s->pos_alt);
             open_on_read = true;
         } else {
@@ -492,7 +510,7 @@ int step_small(nb_sim *s, int nsteps, bool opened)
         else if (!last)
             std::swap(s->pos, s->pos_alt);
     }
-    if (speculate) { s->spec_open = true; s->spec_dt = c.dt; }
+    if (speculate) { s->spec_open = true; s->spec_kind = 1; s->spec_dt = c.dt; }
     s->last_kernel = "small_step_kernel";
     s->last_generic = false;
     return NB_OK;
@@ -506,9 +524,18 @@ int step_run(nb_sim *s, int nsteps)
     bool pending_close = false;     // closing kick of the previous step still to be applied
     bool opened = false;            // the previous step's reduction already did this step's opening kick + drift
     bool packed_by_prev = false;    // ... and repacked the positions for the symmetric kernel
+    bool open_on_read = false;      // this call starts from the previous call's speculative positions (tiled path)
     for (int t = 0; t < nsteps; ++t) {
         // small systems with settled dtypes: one launch per step
         if (!pending_close && small_ok(s)) return step_small(s, nsteps - t, opened);
+        if (t == 0 && s->spec_open && s->spec_kind == 2 && s->spec_dt == s->cfg.dt && s->sym.enabled && !comm_active(s) &&
+            !force_quant_mode(s->cfg) && !grid_mode(s->cfg.mode) && s->pos_alt) {
+            const int sd = s->is_f64 ? NB_F64 : NB_F32;
+            if (s->logical[0] == sd && s->logical[1] == sd && s->logical[3] == sd) {
+                std::swap(s->pos, s->pos_alt);        // positions after this step's drift; `packed` holds them as well
+                opened = packed_by_prev = open_on_read = true;
+            }
+        }
         s->spec_open = false;
         // opening kick + drift; on the pair-symmetric path the repack rides in the same launch
         const int sdt = s->is_f64 ? NB_F64 : NB_F32;
@@ -535,7 +562,11 @@ int step_run(nb_sim *s, int nsteps)
         // between) is folded into the next step's opening launch when there is one
         const bool may_defer = (t + 1 < nsteps) && fuse_pack;
         opened = (t + 1 < nsteps) && uniform_dt;      // request; force_eval answers
-        if (int rc = force_eval(s, true, packed_ready, may_defer ? &pending_close : nullptr, &opened)) return rc;
+        s->req_open_on_read = (t == 0) && open_on_read;
+        s->req_spec_next = (t + 1 == nsteps) && uniform_dt && s->sym.enabled && !s->knobs.no_spec;
+        const int rc_eval = force_eval(s, true, packed_ready, may_defer ? &pending_close : nullptr, &opened);
+        s->req_open_on_read = s->req_spec_next = false;
+        if (rc_eval) return rc_eval;
         packed_by_prev = opened && s->sym.enabled;
         s->logical[1] = promote(s->logical[1], s->logical[3]);
     }
@@ -564,6 +595,7 @@ int energy_eval(nb_sim *s, double *kinetic, double *potential)
             // uniform masses: no mass factor in the pair loop; m * m (rounded like upstream's masses[i] * masses[j], in the
             // masses' dtype) multiplies the finished sum below
             pe_uniform = s->mass_uniform;
+            if (s->spec_kind == 2) s->spec_open = false;      // `packed` (the speculative next positions with it) is rewritten here
             HIPCHK(nb_launch_pack(s->pos, s->vel, s->acc, s->mass, sp.packed, c.n, sp.np, c.dim, s->is_f64, 0, 0.0, 0.0,
                                   1.0, s->is_f64 && s->logical[0] != NB_F64, s->stream, 0, -1, pe_uniform ? 1 : 0));
             HIPCHK(nb_launch_potential_sym(sp.packed, sp.work, sp.nwork, s->scratch, sp.np, c.dim, sp.r, s->is_f64,

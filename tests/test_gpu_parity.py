@@ -2330,14 +2330,16 @@ def test_handle_cache_reuse_is_invisible(nb):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["float64", "float32"])
-def test_step_loop_speculation_is_dropped_by_every_write(nb, monkeypatch, mode):
-    """A Python loop of step() on a small system takes the next step's drifted positions from the previous call
-    (nb_step.cpp: step_small).  Every write in between -- dt, G, softening, positions, velocities, masses,
-    accelerations, an explicit force evaluation -- must void them: the same sequence on the tiled kernels (no
-    speculation there) agrees to rounding, and a step() loop equals one run() call bit for bit."""
+@pytest.mark.parametrize("n", [700, 6000])
+@pytest.mark.parametrize("mode", ["float64", "float32", "bfloat16"])
+def test_step_loop_speculation_is_dropped_by_every_write(nb, monkeypatch, mode, n):
+    """A Python loop of step() takes the next step's drifted positions from the previous native call (nb_step.cpp:
+    step_small for small systems, reduce_sym_kernel's mode 3 on the tiled path).  Every write in between -- dt, G,
+    softening, positions, velocities, masses, accelerations, an explicit force evaluation, a potential-energy evaluation
+    (it rewrites the packed positions) -- must void them: the same sequence with speculation switched off (NB_NO_SPEC)
+    gives bit-identical results, and a step() loop equals one run() call bit for bit."""
     from nbody_cosmological_simulation_amd import galaxy
-    pos, vel, mass = galaxy.create_disk_galaxy(700, seed=11, device="cpu")
+    pos, vel, mass = galaxy.create_disk_galaxy(n, seed=11, device="cpu")
     pm = nb.PrecisionMode(mode)
 
     def script(sim):
@@ -2351,6 +2353,8 @@ def test_step_loop_speculation_is_dropped_by_every_write(nb, monkeypatch, mode):
         sim.step(); out.append(sim.velocities.clone())
         sim.positions[:10] += 0.25                       # in-place edit of the downloaded tensor
         sim.step()
+        out.append(torch.tensor([sim.get_total_energy()], dtype=torch.float64))
+        sim.step()
         sim.softening_sq = 0.02
         sim.masses = sim.masses * 2.0
         sim.step(); out.append(sim.positions.clone())
@@ -2359,26 +2363,27 @@ def test_step_loop_speculation_is_dropped_by_every_write(nb, monkeypatch, mode):
         sim.dt = 0.01
         sim.run(3)
         sim.step()
-        out += [sim.positions.clone(), sim.velocities.clone()]
+        sim.step()
+        out += [sim.positions.clone(), sim.velocities.clone(), sim.accelerations.clone()]
         return out
 
-    a = script(nb.GalaxySimulation(pos, vel, mass, precision_mode=pm))
-    monkeypatch.setenv("NB_NO_SMALLN", "1")
-    tiled = nb.GalaxySimulation(pos, vel, mass, precision_mode=pm)
-    monkeypatch.delenv("NB_NO_SMALLN")
-    b = script(tiled)
-    assert tiled.force_kernel_name() != "small_step_kernel"
-    tol = 1e-11 if mode == "float64" else 2e-5
+    spec = nb.GalaxySimulation(pos, vel, mass, precision_mode=pm)
+    a = script(spec)
+    monkeypatch.setenv("NB_NO_SPEC", "1")
+    plain = nb.GalaxySimulation(pos, vel, mass, precision_mode=pm)
+    monkeypatch.delenv("NB_NO_SPEC")
+    b = script(plain)
+    assert spec.force_kernel_name() == plain.force_kernel_name()
+    assert (spec.force_kernel_name() == "small_step_kernel") == (n == 700)
     for x, y in zip(a, b):
-        assert relerr(x.numpy(), y.numpy()) < tol
+        assert torch.equal(x, y)
     # step() loop == run(): bit for bit, including across reads of the state
     s1 = nb.GalaxySimulation(pos, vel, mass, precision_mode=pm)
     s2 = nb.GalaxySimulation(pos, vel, mass, precision_mode=pm)
     for k in range(7):
         s1.step()
         if k == 3:
-            _ = s1.get_total_energy(), s1.positions
+            _ = s1.get_kinetic_energy(), s1.positions
     s2.run(7)
-    assert s1.force_kernel_name() == "small_step_kernel"
     assert torch.equal(s1.positions, s2.positions) and torch.equal(s1.velocities, s2.velocities)
     assert torch.equal(s1.accelerations, s2.accelerations)

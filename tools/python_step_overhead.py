@@ -5,7 +5,7 @@ sys.path.insert(0, os.getcwd())
 import nbody_cosmological_simulation_amd as nb
 from nbody_cosmological_simulation_amd import galaxy
 
-for n in (1024, 3000, 65536):
+for n in (1024, 3000, 8192, 65536):
     pos, vel, mass = galaxy.create_disk_galaxy(n, seed=1, device="cpu")
     sim = nb.GalaxySimulation(pos.cuda(), vel.cuda(), mass.cuda(), precision_mode=nb.PrecisionMode.FLOAT32)
     sim.run(200); sim.synchronize()
